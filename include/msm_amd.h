@@ -1,0 +1,185 @@
+/* msm_amd.h -- C ABI of the MI355X-native BN254 G1 multi-scalar multiplication (libmsm_amd.so).
+ *
+ * Drop-in boundary for the Apple-Metal MSM path of ElusAegis/metal-msm-gpu-acceleration (crate
+ * `mopro-msm`).  The reference has no C ABI of its own (its callers are generic Rust functions,
+ * src/metal/msm.rs); every entry point below cites the reference interface it replaces, and
+ * INTEGRATION.md shows the Rust `extern "C"` shim a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types;
+ *   - every function returns an int status (0 = OK), never aborts;
+ *   - a ctx owns one HIP device + one stream + a grow-on-demand device workspace; calls on one ctx
+ *     are serialised internally, different ctxs (one per GPU) run concurrently;
+ *   - all 256-bit values are little-endian (least significant byte first) unless a *_BE32 layout
+ *     is named; field coordinates are in Montgomery form with R = 2^256 exactly as halo2curves and
+ *     arkworks hold them in memory.
+ */
+#ifndef MSM_AMD_H
+#define MSM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msm_amd_ctx msm_amd_ctx;
+
+/* Status codes; 1..5 mirror MetalError (src/metal/abstraction/errors.rs:4-19). */
+enum {
+  MSM_AMD_OK = 0,
+  MSM_AMD_DEVICE_NOT_FOUND = 1, /* MetalError::DeviceNotFound */
+  MSM_AMD_LIBRARY_ERROR = 2,    /* MetalError::LibraryError   (code object missing / not gfx950) */
+  MSM_AMD_FUNCTION_ERROR = 3,   /* MetalError::FunctionError  (kernel attribute / symbol) */
+  MSM_AMD_PIPELINE_ERROR = 4,   /* MetalError::PipelineError  (launch / runtime failure) */
+  MSM_AMD_INPUT_ERROR = 5       /* MetalError::InputError     (null, n == 0, bad layout/size) */
+};
+
+/* Scalar layouts (32 bytes each). */
+enum {
+  MSM_AMD_SCALAR_MONT_LE = 0,   /* halo2curves bn256::Fr / ark_bn254::Fr in memory: [u64;4] LE, Montgomery
+                                   (msm.rs:258-270 reinterprets &[C::Scalar]) */
+  MSM_AMD_SCALAR_CANON_LE = 1,  /* canonical integer, little-endian */
+  MSM_AMD_SCALAR_CANON_BE32 = 2 /* reference wire layout: 8 x u32, most significant limb first, canonical
+                                   (limbs_conversion.rs:116-121, :282-288) */
+};
+
+/* Point layouts. */
+enum {
+  MSM_AMD_POINT_H2C_AFFINE = 0,     /* bn256::G1Affine {x,y}: 64 B, Montgomery LE, identity = (0,0) */
+  MSM_AMD_POINT_ARK_PROJECTIVE = 1, /* ark_bn254::G1Projective {x,y,z}: 96 B Jacobian, Montgomery LE
+                                       (limbs_conversion.rs:123-130) */
+  MSM_AMD_POINT_ARK_AFFINE = 2,     /* ark_bn254::G1Affine {x,y,infinity:bool}: 72 B (limbs_conversion.rs:132-137) */
+  MSM_AMD_POINT_JAC_BE32 = 3        /* reference wire layout: 24 x u32 (x,y,z each MS-limb first), Montgomery */
+};
+
+/* Per-stage device times of the last MSM on this ctx, milliseconds, from hipEvents on the ctx stream
+ * (replaces the log::debug! Instant timers of msm.rs:193-214, 288-328). */
+typedef struct msm_amd_timings {
+  float convert_ms;     /* input layout conversion (0 when inputs are already native) */
+  float digits_ms;      /* prepare_buckets_indices */
+  float sort_ms;        /* sort_buckets: hist + prefix + scan + scatter (+ bucket ordering) */
+  float accumulate_ms;  /* bucket_wise_accumulation (dominant kernel) */
+  float reduce_ms;      /* sum_reduction: segment + tree kernels */
+  float final_ms;       /* final_accumulation on the host (wall clock) */
+  float total_gpu_ms;   /* first kernel start -> last kernel end */
+  uint32_t n;
+  uint32_t window_size;
+  uint32_t num_windows;
+  uint32_t reserved;
+} msm_amd_timings;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* setup_metal_state (msm.rs:77-94): pick `device` (ordinal; -1 = current HIP device), create the
+ * stream, check the kernels are loadable. */
+int msm_amd_init(int device, msm_amd_ctx** out);
+/* setup_metal_state_reusable (msm.rs:96-109): process-global cached ctx on the current device. */
+int msm_amd_init_reusable(msm_amd_ctx** out);
+/* get_global_metal_config (msm.rs:114-119): the cached ctx, MSM_AMD_INPUT_ERROR if never initialised. */
+int msm_amd_get_global(msm_amd_ctx** out);
+void msm_amd_destroy(msm_amd_ctx* ctx);
+const char* msm_amd_strerror(int status);
+/* Human-readable detail of the last failure on this ctx (empty string if none). */
+const char* msm_amd_last_error(const msm_amd_ctx* ctx);
+
+/* encode_instances' `window_size: Option<u32>` (msm.rs:130-141): 0 = automatic, else 3..15. */
+int msm_amd_set_window_size(msm_amd_ctx* ctx, uint32_t window_size);
+/* The automatic choice for n points (reference policy: 3 if n < 32 else 15, msm.rs:135-141;
+ * this library: 3 if n < 32 else clamp(floor(log2 n) - 5, 4, 15), equal at n >= 2^20). */
+uint32_t msm_amd_auto_window_size(size_t n);
+
+/* ---- whole-MSM entry points: host buffers ---------------------------------------------------- */
+/* gpu_msm_h2c::<G1Affine, .., Fr>(scalars, points) -> G1 (msm.rs:352-364).
+ * scalars: n x 32 B MSM_AMD_SCALAR_MONT_LE; points: n x 64 B MSM_AMD_POINT_H2C_AFFINE;
+ * out: 96 B Jacobian (x, y, z) Montgomery LE, normalised to z = R mod p, or z = 0 for the identity:
+ * memcpy-compatible with bn256::G1 / G1Projective. */
+int msm_amd_gpu_msm_h2c(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n, void* out96);
+/* metal_msm::<ArkG, ArkFr>(points, scalars, &mut config) -> Result<ArkG, MetalError> (msm.rs:220-234).
+ * points: n x 96 B MSM_AMD_POINT_ARK_PROJECTIVE; scalars: n x 32 B MSM_AMD_SCALAR_MONT_LE. */
+int msm_amd_metal_msm_ark(msm_amd_ctx* ctx, const void* points, const void* scalars, size_t n, void* out96);
+/* Generic form of the two above with explicit layouts. */
+int msm_amd_msm(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const void* scalars, const void* points,
+                size_t n, void* out96);
+/* The instance loop of gpu_profiler / benches (gpu_profiler.rs:104-106, msm_benchmark.rs:29-34):
+ * n_inst independent MSMs; out = n_inst x 96 B. */
+int msm_amd_msm_batch(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
+                      const void* const* scalars, const void* const* points, const size_t* n, void* out);
+
+/* ---- whole-MSM entry points: inputs already resident in device memory ------------------------ */
+/* Same as msm_amd_msm / msm_amd_msm_batch but scalars/points are device pointers on ctx's device
+ * (the reference re-uploads and re-converts per call, msm.rs:152-153; an SRS is uploaded once here). */
+int msm_amd_msm_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const void* d_scalars,
+                       const void* d_points, size_t n, void* out96_host);
+int msm_amd_msm_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
+                             const void* const* d_scalars, const void* const* d_points, const size_t* n,
+                             void* out_host);
+
+/* ---- device memory helpers (so callers without a HIP binding can stage data) ------------------ */
+int msm_amd_device_alloc(msm_amd_ctx* ctx, size_t bytes, void** d_ptr);
+int msm_amd_device_free(msm_amd_ctx* ctx, void* d_ptr);
+int msm_amd_copy_to_device(msm_amd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int msm_amd_copy_to_host(msm_amd_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+/* Raw hipStream_t of the ctx (for event/stream interop from torch or HIP callers). */
+void* msm_amd_stream(msm_amd_ctx* ctx);
+int msm_amd_synchronize(msm_amd_ctx* ctx);
+
+/* Deterministic synthetic instance on the device (role of preprocess.rs:113-138): n uniform random
+ * G1 points (64 B affine, Montgomery) and n uniform scalars (Montgomery if scalars_mont else canonical LE). */
+int msm_amd_generate_instance(msm_amd_ctx* ctx, uint64_t seed, size_t n, int scalars_mont, void* d_points,
+                              void* d_scalars);
+
+/* ---- per-stage entry points in the reference's wire layout (host buffers) ---------------------
+ * These are the `pub` stage functions the reference's own stage tests drive through
+ * create_test_instance (sort_buckets.rs:38-69, bucket_wise_accumulation.rs:154-224,
+ * sum_reduction.rs:210-258). u32 limbs are most-significant-first (MSM_AMD_*_BE32). */
+/* prepare_buckets_indices (prepare_buckets_indices.rs:15-38 + msm.h.metal:17-59): scalars n x 8 u32
+ * canonical BE32 -> pairs n*W x 2 u32 at [t*W + i] = (i*(2^c-1) + m - 1, t) or (0xFFFFFFFF,0xFFFFFFFF). */
+int msm_amd_prepare_buckets_indices(msm_amd_ctx* ctx, const uint32_t* scalars_be32, size_t n, uint32_t window_size,
+                                    uint32_t num_windows, uint32_t* pairs_out);
+/* sort_buckets_indices (sort_buckets.rs:15-34): sort n_pairs (u32,u32) pairs by .0 ascending, in place. */
+int msm_amd_sort_buckets_indices(msm_amd_ctx* ctx, uint32_t* pairs, size_t n_pairs);
+/* bucket_wise_accumulation (bucket_wise_accumulation.rs:26-107): pairs sorted by bucket; points
+ * n_points x 24 u32 Jacobian BE32; buckets_out total_buckets x 24 u32 (untouched buckets = all zero,
+ * i.e. z = 0, as Metal's zero-filled buffers give the reference). */
+int msm_amd_bucket_wise_accumulation(msm_amd_ctx* ctx, const uint32_t* sorted_pairs, size_t n_pairs,
+                                     const uint32_t* points_be32, size_t n_points, uint32_t total_buckets,
+                                     uint32_t* buckets_out);
+/* sum_reduction (sum_reduction.rs:161-181): res[j] = sum_b (b+1) * buckets[j*buckets_size + b]. */
+int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32_t buckets_size,
+                          uint32_t num_windows, uint32_t* res_out);
+/* final_accumulation (final_accumulation.rs:5-40): Horner over the window sums, on the host. */
+int msm_amd_final_accumulation(const uint32_t* res_be32, uint32_t num_windows, uint32_t window_size,
+                               uint32_t* point_out);
+
+/* ---- single-op test kernels (role of the kernels in shader/tests/ and curves/bn254.h.metal) ------------
+ * Batched: `count` independent operations, one lane each.  Operands are 8 x u32 BE32 limbs per 256-bit
+ * value; points are 24 x u32. */
+enum {
+  MSM_AMD_OP_UINT_ADD = 0,  /* test_uint_add   a + b mod 2^256 */
+  MSM_AMD_OP_UINT_SUB = 1,  /* test_uint_sub */
+  MSM_AMD_OP_UINT_PROD = 2, /* test_uint_prod  a * b[low 32 bits] mod 2^256 */
+  MSM_AMD_OP_UINT_SHL = 3,  /* test_uint_shl   a << (b mod 256) */
+  MSM_AMD_OP_UINT_SHR = 4,  /* test_uint_shr */
+  MSM_AMD_OP_FP_ADD = 5,    /* fp_bn254_add (Montgomery residues in and out) */
+  MSM_AMD_OP_FP_SUB = 6,
+  MSM_AMD_OP_FP_MUL = 7,
+  MSM_AMD_OP_FP_NEG = 8,
+  MSM_AMD_OP_FP_POW = 9,    /* a ^ (b low 32 bits) */
+  MSM_AMD_OP_EC_ADD = 10,   /* bn254_add: Jacobian + Jacobian; a, b, out are 24 limbs */
+  MSM_AMD_OP_EC_MUL = 11,   /* bn254_scalar_mul: a = point (24 limbs), b = scalar (8 limbs, canonical) */
+  MSM_AMD_OP_EC_MADD = 12,  /* Jacobian a + affine b (b given as 24 limbs with z = one or z = 0) */
+  MSM_AMD_OP_EC_DBL = 13    /* 2 * a */
+};
+int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count);
+
+/* ---- introspection --------------------------------------------------------------------------- */
+int msm_amd_last_timings(const msm_amd_ctx* ctx, msm_amd_timings* out);
+/* Algorithmic HBM bytes of one MSM: whole pipeline and accumulation only. */
+uint64_t msm_amd_algorithmic_bytes(size_t n, uint32_t window_size, int accumulate_only);
+const char* msm_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSM_AMD_H */

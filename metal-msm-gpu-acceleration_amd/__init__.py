@@ -1,0 +1,287 @@
+"""Python binding of libmsm_amd.so for tests and bench.py (ctypes over the C ABI of include/msm_amd.h).
+
+The product is the C/HIP library; this module only loads it and mirrors the reference's entry-point
+names (`mopro_msm::metal::msm::{gpu_msm_h2c, metal_msm, setup_metal_state, ...}`, src/metal/msm.rs) so
+that tests read like the reference's own.  There is NO CPU fallback: if the library is missing or no
+gfx950 device is present the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsm_amd.so")
+
+OK, DEVICE_NOT_FOUND, LIBRARY_ERROR, FUNCTION_ERROR, PIPELINE_ERROR, INPUT_ERROR = range(6)
+SCALAR_MONT_LE, SCALAR_CANON_LE, SCALAR_CANON_BE32 = 0, 1, 2
+POINT_H2C_AFFINE, POINT_ARK_PROJECTIVE, POINT_ARK_AFFINE, POINT_JAC_BE32 = 0, 1, 2, 3
+POINT_BYTES = {POINT_H2C_AFFINE: 64, POINT_ARK_PROJECTIVE: 96, POINT_ARK_AFFINE: 72, POINT_JAC_BE32: 96}
+(OP_UINT_ADD, OP_UINT_SUB, OP_UINT_PROD, OP_UINT_SHL, OP_UINT_SHR, OP_FP_ADD, OP_FP_SUB, OP_FP_MUL, OP_FP_NEG,
+ OP_FP_POW, OP_EC_ADD, OP_EC_MUL, OP_EC_MADD, OP_EC_DBL) = range(14)
+
+# every symbol include/msm_amd.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "msm_amd_init", "msm_amd_init_reusable", "msm_amd_get_global", "msm_amd_destroy", "msm_amd_strerror",
+    "msm_amd_last_error", "msm_amd_set_window_size", "msm_amd_auto_window_size", "msm_amd_gpu_msm_h2c",
+    "msm_amd_metal_msm_ark", "msm_amd_msm", "msm_amd_msm_batch", "msm_amd_msm_device",
+    "msm_amd_msm_batch_device", "msm_amd_device_alloc", "msm_amd_device_free", "msm_amd_copy_to_device",
+    "msm_amd_copy_to_host", "msm_amd_stream", "msm_amd_synchronize", "msm_amd_generate_instance",
+    "msm_amd_prepare_buckets_indices", "msm_amd_sort_buckets_indices", "msm_amd_bucket_wise_accumulation",
+    "msm_amd_sum_reduction", "msm_amd_final_accumulation", "msm_amd_test_op", "msm_amd_last_timings",
+    "msm_amd_algorithmic_bytes", "msm_amd_version",
+]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [("convert_ms", c_float), ("digits_ms", c_float), ("sort_ms", c_float), ("accumulate_ms", c_float),
+                ("reduce_ms", c_float), ("final_ms", c_float), ("total_gpu_ms", c_float), ("n", c_uint32),
+                ("window_size", c_uint32), ("num_windows", c_uint32), ("reserved", c_uint32)]
+
+
+class MsmError(RuntimeError):
+    """Counterpart of MetalError (src/metal/abstraction/errors.rs:4-19)."""
+
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__(f"msm_amd status {status}: {_lib().msm_amd_strerror(status).decode()} {detail}")
+
+
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = ctypes.CDLL(LIB_PATH)
+        L.msm_amd_strerror.restype = c_char_p
+        L.msm_amd_strerror.argtypes = [c_int]
+        L.msm_amd_last_error.restype = c_char_p
+        L.msm_amd_last_error.argtypes = [c_void_p]
+        L.msm_amd_version.restype = c_char_p
+        L.msm_amd_init.argtypes = [c_int, POINTER(c_void_p)]
+        L.msm_amd_init_reusable.argtypes = [POINTER(c_void_p)]
+        L.msm_amd_get_global.argtypes = [POINTER(c_void_p)]
+        L.msm_amd_destroy.argtypes = [c_void_p]
+        L.msm_amd_destroy.restype = None
+        L.msm_amd_set_window_size.argtypes = [c_void_p, c_uint32]
+        L.msm_amd_auto_window_size.argtypes = [c_size_t]
+        L.msm_amd_auto_window_size.restype = c_uint32
+        L.msm_amd_gpu_msm_h2c.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.msm_amd_metal_msm_ark.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.msm_amd_msm.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.msm_amd_msm_batch.argtypes = [c_void_p, c_int, c_int, c_size_t, POINTER(c_void_p), POINTER(c_void_p),
+                                        POINTER(c_size_t), c_void_p]
+        L.msm_amd_msm_device.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.msm_amd_msm_batch_device.argtypes = [c_void_p, c_int, c_int, c_size_t, POINTER(c_void_p),
+                                               POINTER(c_void_p), POINTER(c_size_t), c_void_p]
+        L.msm_amd_device_alloc.argtypes = [c_void_p, c_size_t, POINTER(c_void_p)]
+        L.msm_amd_device_free.argtypes = [c_void_p, c_void_p]
+        L.msm_amd_copy_to_device.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
+        L.msm_amd_copy_to_host.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
+        L.msm_amd_stream.argtypes = [c_void_p]
+        L.msm_amd_stream.restype = c_void_p
+        L.msm_amd_synchronize.argtypes = [c_void_p]
+        L.msm_amd_generate_instance.argtypes = [c_void_p, c_uint64, c_size_t, c_int, c_void_p, c_void_p]
+        L.msm_amd_prepare_buckets_indices.argtypes = [c_void_p, c_void_p, c_size_t, c_uint32, c_uint32, c_void_p]
+        L.msm_amd_sort_buckets_indices.argtypes = [c_void_p, c_void_p, c_size_t]
+        L.msm_amd_bucket_wise_accumulation.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_uint32,
+                                                       c_void_p]
+        L.msm_amd_sum_reduction.argtypes = [c_void_p, c_void_p, c_uint32, c_uint32, c_void_p]
+        L.msm_amd_final_accumulation.argtypes = [c_void_p, c_uint32, c_uint32, c_void_p]
+        L.msm_amd_test_op.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t]
+        L.msm_amd_last_timings.argtypes = [c_void_p, POINTER(Timings)]
+        L.msm_amd_algorithmic_bytes.argtypes = [c_size_t, c_uint32, c_int]
+        L.msm_amd_algorithmic_bytes.restype = c_uint64
+        _LIB = L
+    return _LIB
+
+
+def lib():
+    return _lib()
+
+
+def _u32buf(seq):
+    arr = (c_uint32 * len(seq))(*seq)
+    return arr
+
+
+class MsmConfig:
+    """MetalMsmConfig (msm.rs:59-63): device + stream + kernels.  `setup_metal_state()` makes one."""
+
+    def __init__(self, device=-1, _handle=None, _owned=True):
+        self._owned = _owned
+        if _handle is not None:
+            self.h = _handle
+            return
+        h = c_void_p()
+        st = _lib().msm_amd_init(device, ctypes.byref(h))
+        if st != OK:
+            raise MsmError(st)
+        self.h = h
+
+    def _check(self, st):
+        if st != OK:
+            raise MsmError(st, _lib().msm_amd_last_error(self.h).decode())
+
+    def close(self):
+        if self.h and self._owned:
+            _lib().msm_amd_destroy(self.h)
+        self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- whole MSM -------------------------------------------------------------------------
+    def set_window_size(self, c):
+        self._check(_lib().msm_amd_set_window_size(self.h, c))
+
+    def msm(self, scalars: bytes, points: bytes, n: int, scalar_layout=SCALAR_MONT_LE,
+            point_layout=POINT_H2C_AFFINE) -> bytes:
+        out = ctypes.create_string_buffer(96)
+        self._check(_lib().msm_amd_msm(self.h, scalar_layout, point_layout, scalars, points, n, out))
+        return out.raw
+
+    def msm_batch(self, scalars_list, points_list, ns, scalar_layout=SCALAR_MONT_LE,
+                  point_layout=POINT_H2C_AFFINE):
+        k = len(ns)
+        sp = (c_void_p * k)(*[ctypes.cast(ctypes.c_char_p(s), c_void_p) for s in scalars_list])
+        pp = (c_void_p * k)(*[ctypes.cast(ctypes.c_char_p(p), c_void_p) for p in points_list])
+        nn = (c_size_t * k)(*ns)
+        out = ctypes.create_string_buffer(96 * k)
+        self._check(_lib().msm_amd_msm_batch(self.h, scalar_layout, point_layout, k, sp, pp, nn, out))
+        return [out.raw[96 * i:96 * i + 96] for i in range(k)]
+
+    def msm_batch_device(self, d_scalars, d_points, ns, scalar_layout=SCALAR_MONT_LE,
+                         point_layout=POINT_H2C_AFFINE):
+        k = len(ns)
+        sp = (c_void_p * k)(*d_scalars)
+        pp = (c_void_p * k)(*d_points)
+        nn = (c_size_t * k)(*ns)
+        out = ctypes.create_string_buffer(96 * k)
+        self._check(_lib().msm_amd_msm_batch_device(self.h, scalar_layout, point_layout, k, sp, pp, nn, out))
+        return [out.raw[96 * i:96 * i + 96] for i in range(k)]
+
+    # ---- device memory ---------------------------------------------------------------------
+    def alloc(self, nbytes) -> int:
+        p = c_void_p()
+        self._check(_lib().msm_amd_device_alloc(self.h, nbytes, ctypes.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        self._check(_lib().msm_amd_device_free(self.h, c_void_p(dptr)))
+
+    def to_device(self, dptr, data: bytes):
+        self._check(_lib().msm_amd_copy_to_device(self.h, c_void_p(dptr), data, len(data)))
+
+    def to_host(self, dptr, nbytes) -> bytes:
+        out = ctypes.create_string_buffer(nbytes)
+        self._check(_lib().msm_amd_copy_to_host(self.h, out, c_void_p(dptr), nbytes))
+        return out.raw
+
+    def generate_instance(self, seed, n, scalars_mont=True):
+        """Device-resident synthetic instance: returns (d_points, d_scalars)."""
+        dp = self.alloc(64 * n)
+        ds = self.alloc(32 * n)
+        self._check(_lib().msm_amd_generate_instance(self.h, seed, n, 1 if scalars_mont else 0, c_void_p(dp),
+                                                     c_void_p(ds)))
+        return dp, ds
+
+    def stream(self) -> int:
+        return _lib().msm_amd_stream(self.h)
+
+    def synchronize(self):
+        self._check(_lib().msm_amd_synchronize(self.h))
+
+    def timings(self) -> Timings:
+        t = Timings()
+        self._check(_lib().msm_amd_last_timings(self.h, ctypes.byref(t)))
+        return t
+
+    # ---- stages (reference wire layout: lists of u32) ----------------------------------------
+    def prepare_buckets_indices(self, scalars_be32, n, window_size, num_windows):
+        out = (c_uint32 * (n * num_windows * 2))()
+        self._check(_lib().msm_amd_prepare_buckets_indices(self.h, _u32buf(scalars_be32), n, window_size,
+                                                           num_windows, out))
+        return [(out[2 * i], out[2 * i + 1]) for i in range(n * num_windows)]
+
+    def sort_buckets_indices(self, pairs):
+        flat = [v for pr in pairs for v in pr]
+        buf = _u32buf(flat)
+        self._check(_lib().msm_amd_sort_buckets_indices(self.h, buf, len(pairs)))
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(len(pairs))]
+
+    def bucket_wise_accumulation(self, sorted_pairs, points_be32, n_points, total_buckets):
+        flat = [v for pr in sorted_pairs for v in pr]
+        out = (c_uint32 * (total_buckets * 24))()
+        self._check(_lib().msm_amd_bucket_wise_accumulation(self.h, _u32buf(flat) if flat else None,
+                                                            len(sorted_pairs), _u32buf(points_be32), n_points,
+                                                            total_buckets, out))
+        return [list(out[24 * i:24 * i + 24]) for i in range(total_buckets)]
+
+    def sum_reduction(self, buckets_be32, buckets_size, num_windows):
+        out = (c_uint32 * (num_windows * 24))()
+        self._check(_lib().msm_amd_sum_reduction(self.h, _u32buf(buckets_be32), buckets_size, num_windows, out))
+        return [list(out[24 * i:24 * i + 24]) for i in range(num_windows)]
+
+    def test_op(self, op, a, b, count):
+        per = 24 if op >= OP_EC_ADD else 8
+        out = (c_uint32 * (count * per))()
+        self._check(_lib().msm_amd_test_op(self.h, op, _u32buf(a), _u32buf(b), out, count))
+        return list(out)
+
+
+def final_accumulation(res_be32, num_windows, window_size):
+    """final_accumulation (final_accumulation.rs:5-40) -- host code in the library, no GPU needed."""
+    out = (c_uint32 * 24)()
+    st = _lib().msm_amd_final_accumulation(_u32buf(res_be32), num_windows, window_size, out)
+    if st != OK:
+        raise MsmError(st)
+    return list(out)
+
+
+# ---- names of the reference API (src/metal/msm.rs) ----------------------------------------------------
+def setup_metal_state(device=-1) -> MsmConfig:
+    """setup_metal_state (msm.rs:77-94)."""
+    return MsmConfig(device)
+
+
+def setup_metal_state_reusable() -> MsmConfig:
+    """setup_metal_state_reusable (msm.rs:96-109): process-global cached config."""
+    h = c_void_p()
+    st = _lib().msm_amd_init_reusable(ctypes.byref(h))
+    if st != OK:
+        raise MsmError(st)
+    return MsmConfig(_handle=h, _owned=False)
+
+
+def get_global_metal_config() -> MsmConfig:
+    """get_global_metal_config (msm.rs:114-119)."""
+    h = c_void_p()
+    st = _lib().msm_amd_get_global(ctypes.byref(h))
+    if st != OK:
+        raise MsmError(st, "MetalMsmConfig must be initialized before use.")
+    return MsmConfig(_handle=h, _owned=False)
+
+
+def gpu_msm_h2c(scalars: bytes, points: bytes, config: MsmConfig | None = None) -> bytes:
+    """gpu_msm_h2c (msm.rs:352-364): bn256::Fr scalars (32 B each) x bn256::G1Affine points (64 B each)."""
+    n = min(len(scalars) // 32, len(points) // 64)
+    cfg = config or setup_metal_state_reusable()
+    out = ctypes.create_string_buffer(96)
+    cfg._check(_lib().msm_amd_gpu_msm_h2c(cfg.h, scalars, points, n, out))
+    return out.raw
+
+
+def metal_msm(points: bytes, scalars: bytes, config: MsmConfig) -> bytes:
+    """metal_msm (msm.rs:220-234): ark G1Projective points (96 B each) x ark Fr scalars."""
+    n = min(len(scalars) // 32, len(points) // 96)
+    out = ctypes.create_string_buffer(96)
+    config._check(_lib().msm_amd_metal_msm_ark(config.h, points, scalars, n, out))
+    return out.raw

@@ -1,0 +1,863 @@
+// Host driver + C ABI of libmsm_amd.so (see include/msm_amd.h).
+//
+// Replaces the reference's L2-L4 layers for the MSM path: MetalState (src/metal/abstraction/state.rs),
+// MetalMsmConfig/Instance + encode_instances + exec_metal_commands + gpu_msm_h2c_sync
+// (src/metal/msm.rs:28-349) and the stage drivers (src/metal/msm/*.rs).  All stages of one MSM are
+// enqueued on ONE HIP stream with no host synchronisation in between (the reference blocks after every
+// stage: prepare_buckets_indices.rs:35-36, bucket_wise_accumulation.rs:104-105, sum_reduction.rs:80-81);
+// the only device->host hand-off is the (c-2)*W partial window points for the host Horner pass.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/msm_amd.h"
+#include "stage_kernels.hip.h"
+
+using namespace msm_amd;
+
+namespace {
+
+constexpr uint32_t kModulusBits = 254;   // limbs_conversion.rs:172, :344
+constexpr uint32_t kMinWindow = 3, kMaxWindow = 15;
+
+struct DeviceBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct Plan {
+  uint32_t n, c, W, nb, Q, chunk, nseg, K, tree_threads;
+  size_t total_buckets, total_segs, partial_count;
+};
+
+enum { EV_START = 0, EV_CONVERT, EV_DIGITS, EV_SORT, EV_ACC, EV_REDUCE, EV_COUNT };
+
+struct InstanceSlot {
+  hipEvent_t ev[EV_COUNT];
+  Jacobian* h_partial = nullptr;   // pinned
+  size_t h_partial_cap = 0;
+  bool has_events = false;
+};
+
+}  // namespace
+
+struct msm_amd_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::string last_error;
+  uint32_t forced_window = 0;
+  DeviceBuf digits, counts, bsize, bstart, sorted, buckets, S, T, partial, conv_scalars, conv_points, scratch_a,
+      scratch_b, scratch_c;
+  std::vector<InstanceSlot> slots;
+  msm_amd_timings timings{};
+};
+
+namespace {
+
+std::mutex g_global_mu;
+msm_amd_ctx* g_global_ctx = nullptr;
+
+int fail(msm_amd_ctx* ctx, int status, const std::string& msg) {
+  if (ctx) ctx->last_error = msg;
+  return status;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      (void)hipGetLastError();                                                                    \
+      return fail(ctx, MSM_AMD_PIPELINE_ERROR,                                                    \
+                  std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" +         \
+                      std::to_string(__LINE__) + ")");                                            \
+    }                                                                                             \
+  } while (0)
+
+int ensure(msm_amd_ctx* ctx, DeviceBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return MSM_AMD_OK;
+  if (b.p) HIP_TRY(ctx, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  // grow by 25% to avoid re-allocating for every slightly larger instance
+  const size_t want = bytes + bytes / 4;
+  HIP_TRY(ctx, hipMalloc(&b.p, want));
+  b.cap = want;
+  return MSM_AMD_OK;
+}
+
+uint32_t floor_log2(size_t n) {
+  uint32_t l = 0;
+  while ((n >> (l + 1)) != 0) ++l;
+  return l;
+}
+
+uint32_t auto_window(size_t n) {
+  if (n < 32) return 3;   // msm.rs:137-138
+  const uint32_t l = floor_log2(n);
+  const uint32_t c = l > 5 ? l - 5 : 0;
+  return std::min(kMaxWindow, std::max(4u, c));
+}
+
+Plan make_plan(size_t n, uint32_t c) {
+  Plan p{};
+  p.n = (uint32_t)n;
+  p.c = c;
+  p.W = (kModulusBits + c - 1) / c;   // window starts 0, c, 2c, ... < 254 (msm.rs:143-146)
+  p.nb = 1u << c;
+  // one 1024-thread workgroup (whole-window LDS histogram) per (chunk, window): aim at ~1 per CU
+  uint32_t Q = std::max(1u, 256u / p.W);
+  const uint32_t max_q = (uint32_t)((n + 4095) / 4096);
+  Q = std::max(1u, std::min(Q, max_q));
+  p.Q = Q;
+  p.chunk = (uint32_t)((n + Q - 1) / Q);
+  p.nseg = p.nb >> kSegLog;
+  p.K = c - kSegLog;
+  p.total_buckets = (size_t)p.W * p.nb;
+  p.total_segs = (size_t)p.W * p.nseg;
+  p.partial_count = (size_t)p.W * (p.K + 1);
+  uint32_t t = 64;
+  while (t < 1024 && t < std::max(1u, p.nseg / 2)) t <<= 1;
+  p.tree_threads = t;
+  return p;
+}
+
+size_t lds_hist_bytes(uint32_t c) { return (size_t)(1u << c) * 4; }
+size_t lds_scan_bytes(uint32_t c) { return ((size_t)(1u << c) + ((1u << c) >> 5) + 32) * 4; }
+
+// ---- host-side big-endian-limb helpers (reference wire layout) ----------------------------------
+u256 be32_to_u256(const uint32_t* l) {
+  u256 r;
+  for (int i = 0; i < 8; ++i) r.v[i] = l[7 - i];
+  return r;
+}
+void u256_to_be32(const u256& a, uint32_t* l) {
+  for (int i = 0; i < 8; ++i) l[i] = a.v[7 - i];
+}
+Jacobian be32_to_jac(const uint32_t* l) {
+  Jacobian r;
+  r.x = be32_to_u256(l);
+  r.y = be32_to_u256(l + 8);
+  r.z = be32_to_u256(l + 16);
+  return r;
+}
+void jac_to_be32(const Jacobian& p, uint32_t* l) {
+  u256_to_be32(p.x, l);
+  u256_to_be32(p.y, l + 8);
+  u256_to_be32(p.z, l + 16);
+}
+
+// Normalise to z = R mod p (or the canonical identity (1,1,0) in Montgomery form).
+Jacobian normalise(const Jacobian& p) {
+  Jacobian r;
+  if (jac_is_identity(p)) return jac_identity();
+  const Affine a = jac_to_affine(p);
+  r.x = a.x;
+  r.y = a.y;
+  r.z = Fq::one();
+  return r;
+}
+
+// Window value  W_w = partial[w][K] + 8 * sum_k 2^k * partial[w][k]   and the final Horner
+// sum_w 2^(c*w) W_w, fused into ONE pass over bit positions: term partial[w][K] sits at bit c*w,
+// partial[w][k] at bit c*w + 3 + k.  Replaces sum_reduction_final + final_accumulation.rs:19-39.
+Jacobian host_combine(const Jacobian* partial, const Plan& p) {
+  const uint32_t top = p.c * p.W;   // exclusive upper bound of bit positions
+  std::vector<std::vector<const Jacobian*>> at(top + 1);
+  for (uint32_t w = 0; w < p.W; ++w) {
+    const Jacobian* pw = partial + (size_t)w * (p.K + 1);
+    at[p.c * w].push_back(&pw[p.K]);
+    for (uint32_t k = 0; k < p.K; ++k) at[p.c * w + kSegLog + k].push_back(&pw[k]);
+  }
+  Jacobian acc = jac_identity();
+  for (int pos = (int)top; pos >= 0; --pos) {
+    acc = jac_double(acc);
+    for (const Jacobian* t : at[pos]) acc = jac_add(acc, *t);
+  }
+  return acc;
+}
+
+int set_kernel_attributes(msm_amd_ctx* ctx) {
+  const int max_lds = 160 * 1024;
+  struct {
+    const void* fn;
+    const char* name;
+  } ks[] = {{(const void*)hist_kernel, "hist_kernel"},
+            {(const void*)scan_kernel, "scan_kernel"},
+            {(const void*)scatter_kernel, "scatter_kernel"},
+            {(const void*)reduce_tree_kernel, "reduce_tree_kernel"}};
+  for (auto& k : ks) {
+    hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ctx, MSM_AMD_FUNCTION_ERROR,
+                  std::string("hipFuncSetAttribute(") + k.name + "): " + hipGetErrorString(e));
+    }
+  }
+  return MSM_AMD_OK;
+}
+
+int slot_prepare(msm_amd_ctx* ctx, InstanceSlot& s, size_t partial_count) {
+  if (!s.has_events) {
+    for (int i = 0; i < EV_COUNT; ++i) HIP_TRY(ctx, hipEventCreate(&s.ev[i]));
+    s.has_events = true;
+  }
+  if (partial_count > s.h_partial_cap) {
+    if (s.h_partial) HIP_TRY(ctx, hipHostFree(s.h_partial));
+    s.h_partial = nullptr;
+    HIP_TRY(ctx, hipHostMalloc((void**)&s.h_partial, partial_count * sizeof(Jacobian), hipHostMallocDefault));
+    s.h_partial_cap = partial_count;
+  }
+  return MSM_AMD_OK;
+}
+
+// Bring inputs to the native device layout (affine 64 B Montgomery LE; scalars 32 B LE).
+// On return *scalars_native / *points_native point to device memory valid until the next call.
+int convert_inputs(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const void* d_scalars,
+                   const void* d_points, size_t n, const u256** scalars_native, int* scalars_mont,
+                   const Affine** points_native) {
+  hipStream_t st = ctx->stream;
+  switch (scalar_layout) {
+    case MSM_AMD_SCALAR_MONT_LE:
+      *scalars_native = (const u256*)d_scalars;
+      *scalars_mont = 1;
+      break;
+    case MSM_AMD_SCALAR_CANON_LE:
+      *scalars_native = (const u256*)d_scalars;
+      *scalars_mont = 0;
+      break;
+    case MSM_AMD_SCALAR_CANON_BE32: {
+      int rc = ensure(ctx, ctx->conv_scalars, n * 32);
+      if (rc) return rc;
+      const size_t words = n;
+      hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)((words * 8 + 255) / 256)), dim3(256), 0, st,
+                         (const uint32_t*)d_scalars, words, (uint32_t*)ctx->conv_scalars.p);
+      *scalars_native = (const u256*)ctx->conv_scalars.p;
+      *scalars_mont = 0;
+      break;
+    }
+    default:
+      return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown scalar layout");
+  }
+  switch (point_layout) {
+    case MSM_AMD_POINT_H2C_AFFINE:
+      *points_native = (const Affine*)d_points;
+      break;
+    case MSM_AMD_POINT_ARK_PROJECTIVE: {
+      int rc = ensure(ctx, ctx->conv_points, n * sizeof(Affine));
+      if (rc) return rc;
+      hipLaunchKernelGGL(projective_to_affine_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st,
+                         (const Jacobian*)d_points, (uint32_t)n, (Affine*)ctx->conv_points.p);
+      *points_native = (const Affine*)ctx->conv_points.p;
+      break;
+    }
+    case MSM_AMD_POINT_ARK_AFFINE: {
+      int rc = ensure(ctx, ctx->conv_points, n * sizeof(Affine));
+      if (rc) return rc;
+      hipLaunchKernelGGL(ark_affine_to_affine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                         (const uint8_t*)d_points, (uint32_t)n, (Affine*)ctx->conv_points.p);
+      *points_native = (const Affine*)ctx->conv_points.p;
+      break;
+    }
+    case MSM_AMD_POINT_JAC_BE32: {
+      int rc = ensure(ctx, ctx->scratch_a, n * sizeof(Jacobian));
+      if (rc) return rc;
+      rc = ensure(ctx, ctx->conv_points, n * sizeof(Affine));
+      if (rc) return rc;
+      const size_t words = n * 3;
+      hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)((words * 8 + 255) / 256)), dim3(256), 0, st,
+                         (const uint32_t*)d_points, words, (uint32_t*)ctx->scratch_a.p);
+      hipLaunchKernelGGL(projective_to_affine_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st,
+                         (const Jacobian*)ctx->scratch_a.p, (uint32_t)n, (Affine*)ctx->conv_points.p);
+      *points_native = (const Affine*)ctx->conv_points.p;
+      break;
+    }
+    default:
+      return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown point layout");
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return MSM_AMD_OK;
+}
+
+size_t scalar_bytes(int) { return 32; }
+size_t point_bytes(int layout) {
+  switch (layout) {
+    case MSM_AMD_POINT_H2C_AFFINE: return 64;
+    case MSM_AMD_POINT_ARK_PROJECTIVE: return 96;
+    case MSM_AMD_POINT_ARK_AFFINE: return 72;
+    case MSM_AMD_POINT_JAC_BE32: return 96;
+  }
+  return 0;
+}
+
+// Window reduction of a production-layout bucket matrix: buckets [W][nb] -> partial [W][K+1] on device.
+int enqueue_reduce(msm_amd_ctx* ctx, const Plan& p, const Jacobian* buckets) {
+  hipStream_t st = ctx->stream;
+  int rc;
+  if ((rc = ensure(ctx, ctx->S, p.total_segs * sizeof(Jacobian)))) return rc;
+  if ((rc = ensure(ctx, ctx->T, p.total_segs * sizeof(Jacobian)))) return rc;
+  if ((rc = ensure(ctx, ctx->partial, p.partial_count * sizeof(Jacobian)))) return rc;
+  hipLaunchKernelGGL(reduce_seg_kernel, dim3((unsigned)((p.total_segs + 63) / 64)), dim3(64), 0, st, buckets,
+                     (uint32_t)p.total_segs, (Jacobian*)ctx->S.p, (Jacobian*)ctx->T.p);
+  hipLaunchKernelGGL(reduce_tree_kernel, dim3(p.K + 1, p.W), dim3(p.tree_threads),
+                     p.tree_threads * sizeof(Jacobian), st, (const Jacobian*)ctx->S.p, (const Jacobian*)ctx->T.p,
+                     p.nseg, p.K, (Jacobian*)ctx->partial.p);
+  HIP_TRY(ctx, hipGetLastError());
+  return MSM_AMD_OK;
+}
+
+// Enqueue one whole MSM on the ctx stream; results land in slot.h_partial after slot.ev[EV_REDUCE].
+int enqueue_msm(msm_amd_ctx* ctx, InstanceSlot& slot, int scalar_layout, int point_layout, const void* d_scalars,
+                const void* d_points, size_t n, Plan* plan_out) {
+  hipStream_t st = ctx->stream;
+  const uint32_t c = ctx->forced_window ? ctx->forced_window : auto_window(n);
+  const Plan p = make_plan(n, c);
+  *plan_out = p;
+  int rc;
+  if ((rc = slot_prepare(ctx, slot, p.partial_count))) return rc;
+  if ((rc = ensure(ctx, ctx->digits, (size_t)p.W * n * sizeof(uint16_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->counts, (size_t)p.W * p.Q * p.nb * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->bsize, p.total_buckets * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->bstart, p.total_buckets * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->sorted, (size_t)p.W * n * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->buckets, p.total_buckets * sizeof(Jacobian)))) return rc;
+
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_START], st));
+  const u256* sc = nullptr;
+  const Affine* pts = nullptr;
+  int sc_mont = 0;
+  if ((rc = convert_inputs(ctx, scalar_layout, point_layout, d_scalars, d_points, n, &sc, &sc_mont, &pts))) return rc;
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_CONVERT], st));
+
+  hipLaunchKernelGGL(digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc, p.n, p.c, p.W, sc_mont,
+                     (uint16_t*)ctx->digits.p);
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_DIGITS], st));
+
+  hipLaunchKernelGGL(hist_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.c), st,
+                     (const uint16_t*)ctx->digits.p, p.n, p.c, p.chunk, (uint32_t*)ctx->counts.p);
+  hipLaunchKernelGGL(chunk_prefix_kernel, dim3((unsigned)((p.total_buckets + 255) / 256)), dim3(256), 0, st,
+                     (uint32_t*)ctx->counts.p, p.c, p.Q, p.W, (uint32_t*)ctx->bsize.p);
+  hipLaunchKernelGGL(scan_kernel, dim3(p.W), dim3(kSortThreads), lds_scan_bytes(p.c), st,
+                     (const uint32_t*)ctx->bsize.p, p.c, (uint32_t*)ctx->bstart.p);
+  hipLaunchKernelGGL(scatter_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.c), st,
+                     (const uint16_t*)ctx->digits.p, p.n, p.c, p.chunk, (const uint32_t*)ctx->counts.p,
+                     (const uint32_t*)ctx->bstart.p, (uint32_t*)ctx->sorted.p);
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_SORT], st));
+
+  hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((p.total_buckets + 63) / 64)), dim3(64), 0, st, pts,
+                     (const uint32_t*)ctx->sorted.p, (const uint32_t*)ctx->bstart.p, (const uint32_t*)ctx->bsize.p,
+                     (const uint32_t*)nullptr, p.n, p.c, (uint32_t)p.total_buckets, (Jacobian*)ctx->buckets.p);
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
+
+  if ((rc = enqueue_reduce(ctx, p, (const Jacobian*)ctx->buckets.p))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial, ctx->partial.p, p.partial_count * sizeof(Jacobian),
+                              hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_REDUCE], st));
+  HIP_TRY(ctx, hipGetLastError());
+  return MSM_AMD_OK;
+}
+
+void accumulate_timings(msm_amd_ctx* ctx, InstanceSlot& s, const Plan& p, float final_ms, size_t n_inst) {
+  float ms[EV_COUNT] = {0};
+  for (int i = 1; i < EV_COUNT; ++i) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, s.ev[i - 1], s.ev[i]) != hipSuccess) {
+      (void)hipGetLastError();
+      t = 0;
+    }
+    ms[i] = t;
+  }
+  msm_amd_timings& T = ctx->timings;
+  const float inv = 1.0f / (float)n_inst;
+  T.convert_ms += ms[EV_CONVERT] * inv;
+  T.digits_ms += ms[EV_DIGITS] * inv;
+  T.sort_ms += ms[EV_SORT] * inv;
+  T.accumulate_ms += ms[EV_ACC] * inv;
+  T.reduce_ms += ms[EV_REDUCE] * inv;
+  T.final_ms += final_ms * inv;
+  T.total_gpu_ms += (ms[EV_CONVERT] + ms[EV_DIGITS] + ms[EV_SORT] + ms[EV_ACC] + ms[EV_REDUCE]) * inv;
+  T.n = p.n;
+  T.window_size = p.c;
+  T.num_windows = p.W;
+  T.reserved = (uint32_t)n_inst;
+}
+
+// Batch of MSMs with device-resident inputs: enqueue everything, then finish each instance on the host as
+// soon as its partials have landed (the host Horner of instance i overlaps the GPU work of i+1..).
+int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
+                     const void* const* d_scalars, const void* const* d_points, const size_t* n, void* out_host) {
+  if (!ctx || !d_scalars || !d_points || !n || !out_host || n_inst == 0)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "null argument or empty batch");
+  if (point_bytes(point_layout) == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown point layout");
+  for (size_t i = 0; i < n_inst; ++i) {
+    if (n[i] == 0 || n[i] > 0x7FFFFFFFull || !d_scalars[i] || !d_points[i])
+      return fail(ctx, MSM_AMD_INPUT_ERROR, "instance with n == 0, n >= 2^31 or null pointer");
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->slots.size() < n_inst) ctx->slots.resize(n_inst);
+  std::vector<Plan> plans(n_inst);
+  ctx->timings = msm_amd_timings{};
+  for (size_t i = 0; i < n_inst; ++i) {
+    int rc = enqueue_msm(ctx, ctx->slots[i], scalar_layout, point_layout, d_scalars[i], d_points[i], n[i], &plans[i]);
+    if (rc) {
+      (void)hipStreamSynchronize(ctx->stream);
+      return rc;
+    }
+  }
+  for (size_t i = 0; i < n_inst; ++i) {
+    InstanceSlot& s = ctx->slots[i];
+    HIP_TRY(ctx, hipEventSynchronize(s.ev[EV_REDUCE]));
+    const auto t0 = std::chrono::steady_clock::now();
+    const Jacobian res = normalise(host_combine(s.h_partial, plans[i]));
+    const float final_ms =
+        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::memcpy((uint8_t*)out_host + i * 96, &res, 96);
+    accumulate_timings(ctx, s, plans[i], final_ms, n_inst);
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM_AMD_OK;
+}
+
+// Host-buffer variant: stage inputs into device scratch, then run the device path per instance.
+int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst, const void* const* scalars,
+                   const void* const* points, const size_t* n, void* out) {
+  if (!ctx || !scalars || !points || !n || !out || n_inst == 0)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "null argument or empty batch");
+  const size_t pb = point_bytes(point_layout);
+  if (pb == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown point layout");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (size_t i = 0; i < n_inst; ++i) {
+    if (n[i] == 0 || !scalars[i] || !points[i]) return fail(ctx, MSM_AMD_INPUT_ERROR, "n == 0 or null pointer");
+    int rc;
+    if ((rc = ensure(ctx, ctx->scratch_b, n[i] * scalar_bytes(scalar_layout)))) return rc;
+    if ((rc = ensure(ctx, ctx->scratch_c, n[i] * pb))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars[i], n[i] * scalar_bytes(scalar_layout),
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, points[i], n[i] * pb, hipMemcpyHostToDevice, ctx->stream));
+    const void* ds = ctx->scratch_b.p;
+    const void* dp = ctx->scratch_c.p;
+    msm_amd_timings keep = ctx->timings;
+    rc = run_batch_device(ctx, scalar_layout, point_layout, 1, &ds, &dp, &n[i], (uint8_t*)out + i * 96);
+    if (rc) return rc;
+    if (i > 0) {   // keep a running per-MSM average over the host-side batch
+      msm_amd_timings& T = ctx->timings;
+      const float a = (float)i / (float)(i + 1), b = 1.0f / (float)(i + 1);
+      T.convert_ms = keep.convert_ms * a + T.convert_ms * b;
+      T.digits_ms = keep.digits_ms * a + T.digits_ms * b;
+      T.sort_ms = keep.sort_ms * a + T.sort_ms * b;
+      T.accumulate_ms = keep.accumulate_ms * a + T.accumulate_ms * b;
+      T.reduce_ms = keep.reduce_ms * a + T.reduce_ms * b;
+      T.final_ms = keep.final_ms * a + T.final_ms * b;
+      T.total_gpu_ms = keep.total_gpu_ms * a + T.total_gpu_ms * b;
+      T.reserved = (uint32_t)(i + 1);
+    }
+  }
+  return MSM_AMD_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* msm_amd_version(void) { return "msm_amd 0.1 (gfx950)"; }
+
+const char* msm_amd_strerror(int status) {
+  switch (status) {
+    case MSM_AMD_OK: return "ok";
+    case MSM_AMD_DEVICE_NOT_FOUND: return "Couldn't find a HIP device (MetalError::DeviceNotFound)";
+    case MSM_AMD_LIBRARY_ERROR: return "Couldn't load the gfx950 code object (MetalError::LibraryError)";
+    case MSM_AMD_FUNCTION_ERROR: return "Couldn't set up a kernel function (MetalError::FunctionError)";
+    case MSM_AMD_PIPELINE_ERROR: return "HIP launch/runtime failure (MetalError::PipelineError)";
+    case MSM_AMD_INPUT_ERROR: return "Invalid input (MetalError::InputError)";
+  }
+  return "unknown status";
+}
+
+const char* msm_amd_last_error(const msm_amd_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int msm_amd_init(int device, msm_amd_ctx** out) {
+  if (!out) return MSM_AMD_INPUT_ERROR;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return MSM_AMD_DEVICE_NOT_FOUND;
+  }
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) return MSM_AMD_DEVICE_NOT_FOUND;
+  }
+  if (device >= count) return MSM_AMD_DEVICE_NOT_FOUND;
+  if (hipSetDevice(device) != hipSuccess) return MSM_AMD_DEVICE_NOT_FOUND;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MSM_AMD_DEVICE_NOT_FOUND;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    // the code object is built for gfx950 only: fail loudly instead of falling back
+    std::fprintf(stderr, "msm_amd: device %d is %s, this library targets gfx950 (MI355X)\n", device,
+                 prop.gcnArchName);
+    return MSM_AMD_LIBRARY_ERROR;
+  }
+  msm_amd_ctx* ctx = new msm_amd_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return MSM_AMD_PIPELINE_ERROR;
+  }
+  int rc = set_kernel_attributes(ctx);
+  if (rc) {
+    std::fprintf(stderr, "msm_amd: %s\n", ctx->last_error.c_str());
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return MSM_AMD_OK;
+}
+
+int msm_amd_init_reusable(msm_amd_ctx** out) {
+  if (!out) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(g_global_mu);
+  if (!g_global_ctx) {
+    int rc = msm_amd_init(-1, &g_global_ctx);
+    if (rc) return rc;
+  }
+  *out = g_global_ctx;
+  return MSM_AMD_OK;
+}
+
+int msm_amd_get_global(msm_amd_ctx** out) {
+  if (!out) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(g_global_mu);
+  if (!g_global_ctx) return MSM_AMD_INPUT_ERROR;
+  *out = g_global_ctx;
+  return MSM_AMD_OK;
+}
+
+void msm_amd_destroy(msm_amd_ctx* ctx) {
+  if (!ctx) return;
+  {
+    std::lock_guard<std::mutex> g(g_global_mu);
+    if (ctx == g_global_ctx) g_global_ctx = nullptr;
+  }
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  DeviceBuf* bufs[] = {&ctx->digits, &ctx->counts, &ctx->bsize, &ctx->bstart, &ctx->sorted, &ctx->buckets, &ctx->S,
+                       &ctx->T, &ctx->partial, &ctx->conv_scalars, &ctx->conv_points, &ctx->scratch_a,
+                       &ctx->scratch_b, &ctx->scratch_c};
+  for (DeviceBuf* b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  for (InstanceSlot& s : ctx->slots) {
+    if (s.has_events)
+      for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(s.ev[i]);
+    if (s.h_partial) (void)hipHostFree(s.h_partial);
+  }
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int msm_amd_set_window_size(msm_amd_ctx* ctx, uint32_t window_size) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  if (window_size != 0 && (window_size < kMinWindow || window_size > kMaxWindow))
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "window_size must be 0 (auto) or 3..15");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->forced_window = window_size;
+  return MSM_AMD_OK;
+}
+
+uint32_t msm_amd_auto_window_size(size_t n) { return auto_window(n); }
+
+int msm_amd_msm_batch(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
+                      const void* const* scalars, const void* const* points, const size_t* n, void* out) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  return run_batch_host(ctx, scalar_layout, point_layout, n_inst, scalars, points, n, out);
+}
+
+int msm_amd_msm(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const void* scalars, const void* points,
+                size_t n, void* out96) {
+  return msm_amd_msm_batch(ctx, scalar_layout, point_layout, 1, &scalars, &points, &n, out96);
+}
+
+int msm_amd_gpu_msm_h2c(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n, void* out96) {
+  return msm_amd_msm(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, scalars, points, n, out96);
+}
+
+int msm_amd_metal_msm_ark(msm_amd_ctx* ctx, const void* points, const void* scalars, size_t n, void* out96) {
+  return msm_amd_msm(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_ARK_PROJECTIVE, scalars, points, n, out96);
+}
+
+int msm_amd_msm_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
+                             const void* const* d_scalars, const void* const* d_points, const size_t* n,
+                             void* out_host) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  return run_batch_device(ctx, scalar_layout, point_layout, n_inst, d_scalars, d_points, n, out_host);
+}
+
+int msm_amd_msm_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const void* d_scalars,
+                       const void* d_points, size_t n, void* out96_host) {
+  return msm_amd_msm_batch_device(ctx, scalar_layout, point_layout, 1, &d_scalars, &d_points, &n, out96_host);
+}
+
+int msm_amd_device_alloc(msm_amd_ctx* ctx, size_t bytes, void** d_ptr) {
+  if (!ctx || !d_ptr || bytes == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "bad device_alloc arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMalloc(d_ptr, bytes));
+  return MSM_AMD_OK;
+}
+
+int msm_amd_device_free(msm_amd_ctx* ctx, void* d_ptr) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipFree(d_ptr));
+  return MSM_AMD_OK;
+}
+
+int msm_amd_copy_to_device(msm_amd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  if (!ctx || !d_dst || !h_src) return fail(ctx, MSM_AMD_INPUT_ERROR, "null pointer");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM_AMD_OK;
+}
+
+int msm_amd_copy_to_host(msm_amd_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  if (!ctx || !h_dst || !d_src) return fail(ctx, MSM_AMD_INPUT_ERROR, "null pointer");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM_AMD_OK;
+}
+
+void* msm_amd_stream(msm_amd_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int msm_amd_synchronize(msm_amd_ctx* ctx) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM_AMD_OK;
+}
+
+int msm_amd_generate_instance(msm_amd_ctx* ctx, uint64_t seed, size_t n, int scalars_mont, void* d_points,
+                              void* d_scalars) {
+  if (!ctx || !d_points || !d_scalars || n == 0 || n > 0x7FFFFFFFull)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "bad generate_instance arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(gen_instance_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, seed,
+                     (uint32_t)n, scalars_mont, (Affine*)d_points, (u256*)d_scalars);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSM_AMD_OK;
+}
+
+// ---- per-stage entry points ------------------------------------------------------------------------
+int msm_amd_prepare_buckets_indices(msm_amd_ctx* ctx, const uint32_t* scalars_be32, size_t n, uint32_t window_size,
+                                    uint32_t num_windows, uint32_t* pairs_out) {
+  if (!ctx || !scalars_be32 || !pairs_out || n == 0 || window_size == 0 || window_size > 32 || num_windows == 0)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "bad prepare_buckets_indices arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  const size_t pair_bytes = n * num_windows * 8;
+  if ((rc = ensure(ctx, ctx->scratch_a, n * 32))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_b, n * 32))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_c, pair_bytes))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, scalars_be32, n * 32, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st,
+                     (const uint32_t*)ctx->scratch_a.p, n, (uint32_t*)ctx->scratch_b.p);
+  hipLaunchKernelGGL(ref_prepare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                     (const u256*)ctx->scratch_b.p, (uint32_t)n, window_size, num_windows, (uint2*)ctx->scratch_c.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(pairs_out, ctx->scratch_c.p, pair_bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return MSM_AMD_OK;
+}
+
+int msm_amd_sort_buckets_indices(msm_amd_ctx* ctx, uint32_t* pairs, size_t n_pairs) {
+  if (!ctx || !pairs) return fail(ctx, MSM_AMD_INPUT_ERROR, "null pointer");
+  if (n_pairs == 0) return MSM_AMD_OK;
+  if (n_pairs > 0xFFFFFFFFull) return fail(ctx, MSM_AMD_INPUT_ERROR, "too many pairs");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  const uint32_t tiles = (uint32_t)((n_pairs + kRadixTile - 1) / kRadixTile);
+  if ((rc = ensure(ctx, ctx->scratch_a, n_pairs * 8))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_b, n_pairs * 8))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_c, (size_t)tiles * 256 * 4))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, pairs, n_pairs * 8, hipMemcpyHostToDevice, st));
+  uint2* src = (uint2*)ctx->scratch_a.p;
+  uint2* dst = (uint2*)ctx->scratch_b.p;
+  for (uint32_t shift = 0; shift < 32; shift += 8) {
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(256), 0, st, (const uint2*)src, n_pairs, shift, tiles,
+                       (uint32_t*)ctx->scratch_c.p);
+    hipLaunchKernelGGL(linear_scan_kernel, dim3(1), dim3(1024), 0, st, (uint32_t*)ctx->scratch_c.p,
+                       (size_t)tiles * 256);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(256), 0, st, (const uint2*)src, dst, n_pairs, shift,
+                       tiles, (const uint32_t*)ctx->scratch_c.p);
+    std::swap(src, dst);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(pairs, src, n_pairs * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return MSM_AMD_OK;
+}
+
+int msm_amd_bucket_wise_accumulation(msm_amd_ctx* ctx, const uint32_t* sorted_pairs, size_t n_pairs,
+                                     const uint32_t* points_be32, size_t n_points, uint32_t total_buckets,
+                                     uint32_t* buckets_out) {
+  if (!ctx || !sorted_pairs || !points_be32 || !buckets_out || n_points == 0 || total_buckets == 0)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "bad bucket_wise_accumulation arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  const size_t pts_bytes = n_points * 96, bkt_bytes = (size_t)total_buckets * 96;
+  if ((rc = ensure(ctx, ctx->scratch_a, std::max(pts_bytes, bkt_bytes)))) return rc;   // BE32 staging
+  if ((rc = ensure(ctx, ctx->scratch_b, pts_bytes))) return rc;                        // points LE
+  if ((rc = ensure(ctx, ctx->scratch_c, std::max<size_t>(n_pairs * 8, 8)))) return rc;
+  if ((rc = ensure(ctx, ctx->buckets, bkt_bytes))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, points_be32, pts_bytes, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)((n_points * 24 + 255) / 256)), dim3(256), 0, st,
+                     (const uint32_t*)ctx->scratch_a.p, n_points * 3, (uint32_t*)ctx->scratch_b.p);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->buckets.p, 0, bkt_bytes, st));   // Appendix B item 8: explicit zero fill
+  if (n_pairs) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, sorted_pairs, n_pairs * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(ref_accumulate_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st,
+                       (const uint2*)ctx->scratch_c.p, n_pairs, (const Jacobian*)ctx->scratch_b.p,
+                       (uint32_t)n_points, total_buckets, (Jacobian*)ctx->buckets.p);
+  }
+  // LE -> BE32 is the same limb reversal
+  hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)(((size_t)total_buckets * 24 + 255) / 256)), dim3(256), 0, st,
+                     (const uint32_t*)ctx->buckets.p, (size_t)total_buckets * 3, (uint32_t*)ctx->scratch_a.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(buckets_out, ctx->scratch_a.p, bkt_bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return MSM_AMD_OK;
+}
+
+int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32_t buckets_size,
+                          uint32_t num_windows, uint32_t* res_out) {
+  if (!ctx || !buckets_be32 || !res_out || buckets_size == 0 || num_windows == 0)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "bad sum_reduction arguments");
+  // production layout needs nb = 2^c > buckets_size (index d carries weight d, d = 0 unused)
+  uint32_t c = kSegLog;
+  while ((1u << c) <= buckets_size) ++c;
+  if (c > 24) return fail(ctx, MSM_AMD_INPUT_ERROR, "buckets_size too large");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  Plan p{};
+  p.c = c;
+  p.W = num_windows;
+  p.nb = 1u << c;
+  p.nseg = p.nb >> kSegLog;
+  p.K = c - kSegLog;
+  p.total_buckets = (size_t)p.W * p.nb;
+  p.total_segs = (size_t)p.W * p.nseg;
+  p.partial_count = (size_t)p.W * (p.K + 1);
+  uint32_t t = 64;
+  while (t < 1024 && t < std::max(1u, p.nseg / 2)) t <<= 1;
+  p.tree_threads = t;
+  int rc;
+  const size_t in_bytes = (size_t)buckets_size * num_windows * 96;
+  if ((rc = ensure(ctx, ctx->scratch_a, in_bytes))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_b, in_bytes))) return rc;
+  if ((rc = ensure(ctx, ctx->buckets, p.total_buckets * sizeof(Jacobian)))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, buckets_be32, in_bytes, hipMemcpyHostToDevice, st));
+  const size_t words = (size_t)buckets_size * num_windows * 3;
+  hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)((words * 8 + 255) / 256)), dim3(256), 0, st,
+                     (const uint32_t*)ctx->scratch_a.p, words, (uint32_t*)ctx->scratch_b.p);
+  hipLaunchKernelGGL(pad_buckets_kernel, dim3((unsigned)((p.total_buckets + 255) / 256)), dim3(256), 0, st,
+                     (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.c, (Jacobian*)ctx->buckets.p);
+  if ((rc = enqueue_reduce(ctx, p, (const Jacobian*)ctx->buckets.p))) return rc;
+  std::vector<Jacobian> partial(p.partial_count);
+  HIP_TRY(ctx, hipMemcpyAsync(partial.data(), ctx->partial.p, p.partial_count * sizeof(Jacobian),
+                              hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  // per-window value: reuse the fused Horner with a single window
+  Plan one = p;
+  one.W = 1;
+  for (uint32_t w = 0; w < num_windows; ++w) {
+    const Jacobian r = host_combine(partial.data() + (size_t)w * (p.K + 1), one);
+    jac_to_be32(r, res_out + (size_t)w * 24);
+  }
+  return MSM_AMD_OK;
+}
+
+int msm_amd_final_accumulation(const uint32_t* res_be32, uint32_t num_windows, uint32_t window_size,
+                               uint32_t* point_out) {
+  if (!res_be32 || !point_out || num_windows == 0) return MSM_AMD_INPUT_ERROR;
+  Jacobian acc = jac_identity();
+  for (int w = (int)num_windows - 1; w >= 0; --w) {
+    for (uint32_t i = 0; i < window_size; ++i) acc = jac_double(acc);
+    acc = jac_add(acc, be32_to_jac(res_be32 + (size_t)w * 24));
+  }
+  jac_to_be32(acc, point_out);
+  return MSM_AMD_OK;
+}
+
+int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count) {
+  if (!ctx || !a || !b || !out || count == 0 || op < 0 || op > MSM_AMD_OP_EC_DBL)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "bad test_op arguments");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const bool pt = op >= MSM_AMD_OP_EC_ADD;
+  const size_t wa = pt ? 3 : 1;
+  const size_t wb = (op == MSM_AMD_OP_EC_MUL) ? 1 : wa;
+  const size_t wo = wa;
+  // host-side limb reversal (tiny inputs), device buffers in LE
+  std::vector<uint32_t> la(count * wa * 8), lb(count * wb * 8), lo(count * wo * 8);
+  for (size_t i = 0; i < count * wa; ++i)
+    for (int l = 0; l < 8; ++l) la[i * 8 + l] = a[i * 8 + 7 - l];
+  for (size_t i = 0; i < count * wb; ++i)
+    for (int l = 0; l < 8; ++l) lb[i * 8 + l] = b[i * 8 + 7 - l];
+  int rc;
+  if ((rc = ensure(ctx, ctx->scratch_a, la.size() * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_b, lb.size() * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_c, lo.size() * 4))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, la.data(), la.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, lb.data(), lb.size() * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(test_op_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, op,
+                     (const u256*)ctx->scratch_a.p, (const u256*)ctx->scratch_b.p, (u256*)ctx->scratch_c.p,
+                     (uint32_t)count);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(lo.data(), ctx->scratch_c.p, lo.size() * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  for (size_t i = 0; i < count * wo; ++i)
+    for (int l = 0; l < 8; ++l) out[i * 8 + l] = lo[i * 8 + 7 - l];
+  return MSM_AMD_OK;
+}
+
+int msm_amd_last_timings(const msm_amd_ctx* ctx, msm_amd_timings* out) {
+  if (!ctx || !out) return MSM_AMD_INPUT_ERROR;
+  *out = ctx->timings;
+  return MSM_AMD_OK;
+}
+
+uint64_t msm_amd_algorithmic_bytes(size_t n, uint32_t window_size, int accumulate_only) {
+  // A(n) = 32n + 72nW + 2*96*totB ; A3(n) = 72nW + 96*totB, with
+  // totB = W * (2^c - 1), 64-byte affine bases, 8-byte (bucket, point) pairs, 96-byte buckets.
+  const uint64_t c = window_size ? window_size : auto_window(n);
+  const uint64_t W = (kModulusBits + c - 1) / c;
+  const uint64_t totB = W * ((1ull << c) - 1);
+  if (accumulate_only) return 72ull * n * W + 96ull * totB;
+  return 32ull * n + 72ull * n * W + 2ull * 96ull * totB;
+}
+
+}  // extern "C"

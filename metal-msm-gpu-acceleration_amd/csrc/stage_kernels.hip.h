@@ -1,0 +1,212 @@
+// Kernels behind the per-stage C-ABI entry points (reference wire semantics) and the single-op test
+// kernels.  Included by msm_host.hip.
+//
+//   ref_prepare_kernel      == kernel prepare_buckets_indices (msm.h.metal:17-59) output format
+//   radix_*_kernel          stand-alone device sort of (u32 key, u32 value) pairs: the stage the
+//                           reference left on the CPU (sort_buckets.rs:15-34).  LSD radix, 8 bits per
+//                           pass, wave64 ballot ranking + LDS prefix sums, stable.
+//   ref_accumulate_kernel   == kernel bucket_wise_accumulation (msm.h.metal:75-315) on Jacobian inputs
+//   pad_buckets_kernel      feeds the production window reduction from a reference-layout bucket matrix
+//   test_op_kernel          == the 12 single-thread test kernels of shader/tests/*.h.metal, batched
+#pragma once
+#include "msm_kernels.hip.h"
+
+namespace msm_amd {
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+ref_prepare_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
+                   uint2* __restrict__ pairs) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const u256 k = load_u256(&scalars[t]);
+  const uint32_t bl = (c >= 32) ? 0xFFFFFFFFu : ((1u << c) - 1u);
+  for (uint32_t i = 0; i < W; ++i) {
+    const uint32_t start = i * c;
+    const uint32_t m = (start < 256) ? u256_extract_bits(k, start, c) : 0u;
+    uint2 pr;
+    if (m != 0) {
+      pr.x = i * bl + m - 1;
+      pr.y = t;
+    } else {
+      pr.x = 0xFFFFFFFFu;
+      pr.y = 0xFFFFFFFFu;
+    }
+    pairs[(size_t)t * W + i] = pr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LSD radix sort, one pass = hist + scan + scatter.  Tile = 256 threads x kRadixItems items; each
+// wave owns a contiguous quarter of the tile so that wave order == memory order (stability).
+constexpr int kRadixItems = 16;
+constexpr int kRadixTile = 256 * kRadixItems;
+
+__global__ void __launch_bounds__(256)
+radix_hist_kernel(const uint2* __restrict__ in, size_t n, uint32_t shift, uint32_t num_tiles,
+                  uint32_t* __restrict__ tile_hist /* [256][num_tiles] */) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * kRadixTile;
+  for (int r = 0; r < kRadixItems; ++r) {
+    const size_t i = base + (size_t)r * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&h[(in[i].x >> shift) & 0xFFu], 1u);
+  }
+  __syncthreads();
+  tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// Exclusive scan of a linear u32 array by ONE workgroup of 1024 threads (in place).
+__global__ void __launch_bounds__(1024)
+linear_scan_kernel(uint32_t* __restrict__ data, size_t len) {
+  __shared__ uint32_t scratch[17];
+  const size_t per = (len + blockDim.x - 1) / blockDim.x;
+  const size_t first = (size_t)threadIdx.x * per;
+  uint32_t local = 0;
+  for (size_t j = 0; j < per; ++j)
+    if (first + j < len) local += data[first + j];
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(local, scratch, &total);
+  for (size_t j = 0; j < per; ++j) {
+    if (first + j < len) {
+      const uint32_t v = data[first + j];
+      data[first + j] = run;
+      run += v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+radix_scatter_kernel(const uint2* __restrict__ in, uint2* __restrict__ out, size_t n, uint32_t shift,
+                     uint32_t num_tiles, const uint32_t* __restrict__ tile_offset /* [256][num_tiles] */) {
+  __shared__ uint32_t wh[4][256];   // per-wave digit counts, then per-wave running write positions
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int v = 0; v < 4; ++v) wh[v][threadIdx.x] = 0;
+  __syncthreads();
+  const size_t wbase = (size_t)blockIdx.x * kRadixTile + (size_t)wave * (kRadixTile / 4);
+  for (int r = 0; r < kRadixItems; ++r) {
+    const size_t i = wbase + (size_t)r * 64 + lane;
+    if (i < n) atomicAdd(&wh[wave][(in[i].x >> shift) & 0xFFu], 1u);
+  }
+  __syncthreads();
+  {
+    // thread d turns the four per-wave counts of digit d into write positions
+    uint32_t run = tile_offset[(size_t)threadIdx.x * num_tiles + blockIdx.x];
+    for (int v = 0; v < 4; ++v) {
+      const uint32_t cnt = wh[v][threadIdx.x];
+      wh[v][threadIdx.x] = run;
+      run += cnt;
+    }
+  }
+  __syncthreads();
+  for (int r = 0; r < kRadixItems; ++r) {
+    const size_t i = wbase + (size_t)r * 64 + lane;
+    const bool valid = i < n;
+    uint2 item = make_uint2(0, 0);
+    if (valid) item = in[i];
+    const uint32_t d = (item.x >> shift) & 0xFFu;
+    // lanes holding the same digit: intersect 8 ballots (wavefront ballot ranking)
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const unsigned long long bal = __ballot((d >> bit) & 1u);
+      same &= ((d >> bit) & 1u) ? bal : ~bal;
+    }
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t rank = __popcll(same & lt);
+    uint32_t pos = 0;
+    if (valid) pos = wh[wave][d] + rank;
+    // the lowest lane of each digit group advances the wave's cursor (same-wave LDS ops are ordered)
+    if (valid && rank == 0) wh[wave][d] += __popcll(same);
+    if (valid) out[pos] = item;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Segmented sum of Jacobian points by sorted bucket key.  One thread per pair; the thread holding the
+// first pair of a run accumulates the run.  Sentinel keys (0xFFFFFFFF) and keys >= total_buckets are
+// skipped like the reference's CPU mirror (bucket_wise_accumulation.rs:671-678).
+__global__ void __launch_bounds__(64)
+ref_accumulate_kernel(const uint2* __restrict__ pairs, size_t n_pairs, const Jacobian* __restrict__ points,
+                      uint32_t n_points, uint32_t total_buckets, Jacobian* __restrict__ buckets) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const uint32_t key = pairs[i].x;
+  if (key == 0xFFFFFFFFu || key >= total_buckets) return;
+  if (i > 0 && pairs[i - 1].x == key) return;
+  Jacobian acc = jac_identity();
+#pragma unroll 1
+  for (size_t j = i; j < n_pairs && pairs[j].x == key; ++j) {
+    const uint32_t pi = pairs[j].y;
+    if (pi < n_points) acc = jac_add(acc, load_jac(&points[pi]));
+  }
+  store_jac(&buckets[key], acc);
+}
+
+// Reference bucket matrix [W][bs] (weight of column b is b+1) -> production layout [W][nb], entry d has
+// weight d: X[w][d] = B[w][d-1] for 1 <= d <= bs, identity elsewhere.
+__global__ void __launch_bounds__(256)
+pad_buckets_kernel(const Jacobian* __restrict__ in, uint32_t bs, uint32_t W, uint32_t c,
+                   Jacobian* __restrict__ out) {
+  const uint32_t nb = 1u << c;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= W * nb) return;
+  const uint32_t w = t >> c, d = t & (nb - 1);
+  Jacobian v = jac_identity();
+  if (d >= 1 && d <= bs) v = load_jac(&in[(size_t)w * bs + d - 1]);
+  store_jac(&out[t], v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched single-op kernel.  a, b, out are little-endian device copies; stride in u256 units is 1 for
+// integer/field ops and 3 for points.
+__global__ void __launch_bounds__(64)
+test_op_kernel(int op, const u256* __restrict__ a, const u256* __restrict__ b, u256* __restrict__ out,
+               uint32_t count) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  if (op <= 9) {
+    const u256 x = load_u256(&a[t]);
+    const u256 y = load_u256(&b[t]);
+    u256 r = u256_zero();
+    switch (op) {
+      case 0: u256_add(r, x, y); break;
+      case 1: u256_sub(r, x, y); break;
+      case 2: r = u256_mul_u32(x, y.v[0]); break;
+      case 3: r = u256_shl(x, y.v[0] & 255u); break;
+      case 4: r = u256_shr(x, y.v[0] & 255u); break;
+      case 5: r = Fq::add(x, y); break;
+      case 6: r = Fq::sub(x, y); break;
+      case 7: r = Fq::mul(x, y); break;
+      case 8: r = Fq::neg(x); break;
+      case 9: r = Fq::pow_u32(x, y.v[0]); break;
+    }
+    store_u256(&out[t], r);
+    return;
+  }
+  const Jacobian p = load_jac(reinterpret_cast<const Jacobian*>(a) + t);
+  Jacobian r = jac_identity();
+  if (op == 10) {
+    const Jacobian q = load_jac(reinterpret_cast<const Jacobian*>(b) + t);
+    r = jac_add(p, q);
+  } else if (op == 11) {
+    const u256 k = load_u256(&b[t]);
+    r = jac_scalar_mul(p, k);
+  } else if (op == 12) {
+    const Jacobian q = load_jac(reinterpret_cast<const Jacobian*>(b) + t);
+    if (jac_is_identity(q)) {
+      r = p;
+    } else {
+      Affine qa;
+      qa.x = q.x;
+      qa.y = q.y;
+      r = jac_madd(p, qa);
+    }
+  } else if (op == 13) {
+    r = jac_double(p);
+  }
+  store_jac(reinterpret_cast<Jacobian*>(out) + t, r);
+}
+
+}  // namespace msm_amd

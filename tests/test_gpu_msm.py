@@ -1,0 +1,144 @@
+"""End-to-end MSM parity: HIP path vs the CPU oracle on the same inputs, compared as canonical affine
+(x, y) -- the reference's criterion (src/metal/msm.rs:604-608, :555-558)."""
+import random
+
+import pytest
+
+from oracle import bn254_ref as o
+from helpers import h2c_instance_bytes, small_instance
+
+pytestmark = pytest.mark.gpu
+
+
+def _expect(points, scalars):
+    return o.msm_pippenger(scalars, points, 8) if len(points) > 64 else o.msm_naive(scalars, points)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 100, 257, 1000])
+def test_gpu_msm_h2c_small(cfg, msm_pkg, n):
+    pts, sc = small_instance(100 + n, n)
+    sb, pb = h2c_instance_bytes(pts, sc)
+    out = msm_pkg.gpu_msm_h2c(sb, pb, cfg)
+    assert o.decode_jacobian_mont_le(out) == _expect(pts, sc)
+    # output is normalised: z == R mod p (or 0)
+    z = int.from_bytes(out[64:96], "little")
+    assert z in (0, o.MONT_R % o.P)
+
+
+@pytest.mark.parametrize("c", [3, 4, 7, 8, 11, 13, 15])
+def test_window_sizes_agree(cfg, msm_pkg, c):
+    pts, sc = small_instance(7, 300)
+    sb, pb = h2c_instance_bytes(pts, sc)
+    cfg.set_window_size(c)
+    try:
+        out = msm_pkg.gpu_msm_h2c(sb, pb, cfg)
+    finally:
+        cfg.set_window_size(0)
+    assert o.decode_jacobian_mont_le(out) == _expect(pts, sc)
+
+
+def test_edge_scalars_and_points(cfg, msm_pkg):
+    rng = random.Random(5)
+    pts, sc = small_instance(9, 200)
+    # zero scalars, scalar 1, r-1, repeated points, P and -P with equal scalars, identity points
+    sc[0] = 0
+    sc[1] = 1
+    sc[2] = o.R_ORDER - 1
+    for i in range(10, 40):
+        sc[i] = 0
+    pts[50] = pts[51] = pts[52]
+    sc[50] = sc[51] = sc[52]                 # same bucket in every window -> P+P doubling path
+    pts[60] = o.aff_neg(pts[61])
+    sc[60] = sc[61]                          # P + (-P) inside a bucket
+    pts[70] = None                           # halo2curves identity (0,0)
+    pts[71] = None
+    sc[80] = (1 << 14) + 1                   # the reference's "breaking scalar" (prepare_buckets_indices.rs:132-135)
+    sb, pb = h2c_instance_bytes(pts, sc)
+    for c in (0, 15, 5):
+        cfg.set_window_size(c)
+        try:
+            out = msm_pkg.gpu_msm_h2c(sb, pb, cfg)
+        finally:
+            cfg.set_window_size(0)
+        assert o.decode_jacobian_mont_le(out) == o.msm_pippenger(sc, pts, 8)
+
+
+def test_all_zero_scalars_gives_identity(cfg, msm_pkg):
+    pts, _ = small_instance(3, 64)
+    sb, pb = h2c_instance_bytes(pts, [0] * 64)
+    out = msm_pkg.gpu_msm_h2c(sb, pb, cfg)
+    assert o.decode_jacobian_mont_le(out) is None
+
+
+def test_all_scalars_equal_skewed_buckets(cfg, msm_pkg):
+    """One bucket per window holds every point (load-balance worst case, SURVEY section 7 hard part 2)."""
+    pts, _ = small_instance(4, 500)
+    k = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % o.R_ORDER
+    sb, pb = h2c_instance_bytes(pts, [k] * 500)
+    out = msm_pkg.gpu_msm_h2c(sb, pb, cfg)
+    acc = None
+    for p in pts:
+        acc = o.jac_add(acc, o.to_jac(p))
+    assert o.decode_jacobian_mont_le(out) == o.scalar_mul(k, o.to_affine(acc))
+
+
+def test_layouts_agree(cfg, msm_pkg):
+    """ark projective / ark affine / reference BE32 wire layout give the same result as h2c."""
+    rng = random.Random(21)
+    pts, sc = small_instance(33, 150)
+    pts[5] = None
+    expect = _expect(pts, sc)
+    # ark projective with random z (metal_msm, msm.rs:220)
+    from helpers import rand_jac
+    proj = b"".join(o.encode_projective_ark(rand_jac(rng, p)) for p in pts)
+    sb = b"".join(o.encode_scalar_h2c(k) for k in sc)
+    assert o.decode_jacobian_mont_le(msm_pkg.metal_msm(proj, sb, cfg)) == expect
+    # ark affine {x, y, infinity}
+    aff = b""
+    for p in pts:
+        if p is None:
+            aff += bytes(64) + b"\x01" + bytes(7)
+        else:
+            aff += o.encode_affine_h2c(p) + bytes(8)
+    out = cfg.msm(sb, aff, len(pts), msm_pkg.SCALAR_MONT_LE, msm_pkg.POINT_ARK_AFFINE)
+    assert o.decode_jacobian_mont_le(out) == expect
+    # reference wire layout: canonical BE32 scalars, Jacobian BE32 points
+    import struct
+    sbe = b"".join(struct.pack("<8I", *o.encode_scalar_be32(k)) for k in sc)
+    pbe = b"".join(struct.pack("<24I", *o.encode_point_be32(rand_jac(rng, p))) for p in pts)
+    out = cfg.msm(sbe, pbe, len(pts), msm_pkg.SCALAR_CANON_BE32, msm_pkg.POINT_JAC_BE32)
+    assert o.decode_jacobian_mont_le(out) == expect
+    # canonical LE scalars
+    scl = b"".join(o.int_to_le_bytes32(k) for k in sc)
+    pb = b"".join(o.encode_affine_h2c(p) for p in pts)
+    out = cfg.msm(scl, pb, len(pts), msm_pkg.SCALAR_CANON_LE, msm_pkg.POINT_H2C_AFFINE)
+    assert o.decode_jacobian_mont_le(out) == expect
+
+
+def test_batch_and_errors(cfg, msm_pkg):
+    insts = [small_instance(40 + i, n) for i, n in enumerate([17, 64, 129])]
+    enc = [h2c_instance_bytes(p, s) for p, s in insts]
+    outs = cfg.msm_batch([e[0] for e in enc], [e[1] for e in enc], [17, 64, 129])
+    for (p, s), out in zip(insts, outs):
+        assert o.decode_jacobian_mont_le(out) == _expect(p, s)
+    with pytest.raises(msm_pkg.MsmError) as ei:
+        cfg.msm(b"", b"", 0)
+    assert ei.value.status == msm_pkg.INPUT_ERROR
+    with pytest.raises(msm_pkg.MsmError):
+        cfg.set_window_size(16)
+
+
+def test_device_generator_matches_oracle(cfg, msm_pkg):
+    n = 64
+    dp, ds = cfg.generate_instance(o.SEED_BASE + 3, n, True)
+    try:
+        pb = cfg.to_host(dp, 64 * n)
+        sb = cfg.to_host(ds, 32 * n)
+        pts, sc = o.gen_instance(o.SEED_BASE + 3, n)
+        assert pb == b"".join(o.encode_affine_h2c(p) for p in pts)
+        assert sb == b"".join(o.encode_scalar_h2c(k) for k in sc)
+        out = cfg.msm_batch_device([ds], [dp], [n])[0]
+        assert o.decode_jacobian_mont_le(out) == o.msm_naive(sc, pts)
+    finally:
+        cfg.free(dp)
+        cfg.free(ds)
