@@ -1,0 +1,151 @@
+// gpu_profiler -- C++ counterpart of the reference CLI (src/bin/gpu_profiler.rs:17-172), same positional
+// arguments and the same two report lines:
+//
+//   gpu_profiler [log_size=16] [num_instances=1] [mode=gpu] [retries=3] [parallel=false]
+//                [--seed S] [--device D] [--window C] [--json]
+//
+// Modes (gpu_profiler.rs:143-172)
+//   gpu       metal::msm::gpu_msm_h2c      -> msm_amd_gpu_msm_h2c (host buffers, upload included)
+//   gpu_cpu   metal::msm::gpu_with_cpu     -> NOT built yet: reported as an error
+//   best_gpu  metal::msm_best              -> NOT built yet (row N1)
+//   cpu       halo2curves::msm::msm_best   -> needs the CPU oracle, which is test infrastructure and is
+//                                             deliberately not linked into product binaries; use bench.py's
+//                                             cpu_baseline leg or tests instead
+//   check     gpu vs cpu equality          -> same restriction as `cpu`
+// Extra mode
+//   gpu_resident   inputs generated once on the device (msm_amd_generate_instance) and kept resident: the
+//                  configuration the headline metric is quoted on.
+//
+// Instances are generated on the device with the deterministic generator (role of
+// preprocess.rs:143-202's instance cache) and copied to the host for the host-buffer modes.
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/msm_amd.h"
+
+static void die(msm_amd_ctx* ctx, int st, const char* what) {
+  std::fprintf(stderr, "[ERROR] %s: %s %s\n", what, msm_amd_strerror(st), ctx ? msm_amd_last_error(ctx) : "");
+  std::exit(1);
+}
+
+int main(int argc, char** argv) {
+  std::vector<std::string> pos;
+  uint64_t seed = 0xB2540000ull;
+  int device = -1, window = 0;
+  bool json = false;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 0);
+    else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+    else if (a == "--window" && i + 1 < argc) window = std::atoi(argv[++i]);
+    else if (a == "--json") json = true;
+    else pos.push_back(a);
+  }
+  // positional parsing with the reference's defaults (gpu_profiler.rs:24-63)
+  const unsigned log_size = pos.size() > 0 ? (unsigned)std::strtoul(pos[0].c_str(), nullptr, 10) : 16;
+  const unsigned num_instances = pos.size() > 1 ? (unsigned)std::strtoul(pos[1].c_str(), nullptr, 10) : 1;
+  std::string mode = pos.size() > 2 ? pos[2] : "gpu";
+  for (auto& ch : mode) ch = (char)std::tolower(ch);
+  const unsigned retries = pos.size() > 3 ? (unsigned)std::strtoul(pos[3].c_str(), nullptr, 10) : 3;
+  const bool parallel = pos.size() > 4 && pos[4] == "true";
+  std::fprintf(stderr, "[INFO] Log instance size: %u\n[INFO] Number of instances: %u\n[INFO] Run mode: %s\n"
+                       "[INFO] Retries: %u\n[INFO] Parallel runs: %s\n",
+               log_size, num_instances, mode.c_str(), retries, parallel ? "true" : "false");
+  if (log_size == 0 || log_size > 28 || num_instances == 0 || retries == 0) {
+    std::fprintf(stderr, "[ERROR] bad arguments\n");
+    return 1;
+  }
+  if (mode == "cpu" || mode == "check") {
+    std::fprintf(stderr, "[ERROR] RUN_MODE %s needs the CPU oracle, which is not linked into product binaries; "
+                         "run `python bench.py` (cpu_baseline) or the tests\n", mode.c_str());
+    return 1;
+  }
+  if (mode == "gpu_cpu" || mode == "best_gpu") {
+    std::fprintf(stderr, "[ERROR] RUN_MODE %s (hybrid front-end, msm.rs:366-445) is not built yet\n", mode.c_str());
+    return 1;
+  }
+  if (mode != "gpu" && mode != "gpu_resident") {
+    std::fprintf(stderr, "[ERROR] Invalid RUN_MODE: %s\n", mode.c_str());   // gpu_profiler.rs:167-170
+    return 1;
+  }
+  if (parallel)
+    std::fprintf(stderr, "[INFO] parallel=true: instances go through ONE batched call (the reference's random "
+                         "chunk/sleep harness, gpu_profiler.rs:107-131, is not reproduced)\n");
+
+  msm_amd_ctx* ctx = nullptr;
+  int st = msm_amd_init(device, &ctx);
+  if (st) die(nullptr, st, "msm_amd_init");
+  if (window && (st = msm_amd_set_window_size(ctx, (uint32_t)window))) die(ctx, st, "set_window_size");
+
+  const size_t n = (size_t)1 << log_size;
+  std::vector<void*> d_pts(num_instances), d_sc(num_instances);
+  std::vector<std::vector<uint8_t>> h_pts, h_sc;
+  for (unsigned j = 0; j < num_instances; ++j) {
+    if ((st = msm_amd_device_alloc(ctx, n * 64, &d_pts[j]))) die(ctx, st, "device_alloc");
+    if ((st = msm_amd_device_alloc(ctx, n * 32, &d_sc[j]))) die(ctx, st, "device_alloc");
+    if ((st = msm_amd_generate_instance(ctx, seed + j, n, 1, d_pts[j], d_sc[j]))) die(ctx, st, "generate_instance");
+  }
+  if (mode == "gpu") {
+    h_pts.resize(num_instances);
+    h_sc.resize(num_instances);
+    for (unsigned j = 0; j < num_instances; ++j) {
+      h_pts[j].resize(n * 64);
+      h_sc[j].resize(n * 32);
+      if ((st = msm_amd_copy_to_host(ctx, h_pts[j].data(), d_pts[j], n * 64))) die(ctx, st, "copy_to_host");
+      if ((st = msm_amd_copy_to_host(ctx, h_sc[j].data(), d_sc[j], n * 32))) die(ctx, st, "copy_to_host");
+    }
+  }
+  std::vector<uint8_t> out((size_t)num_instances * 96);
+  std::vector<const void*> sp(num_instances), pp(num_instances);
+  std::vector<size_t> ns(num_instances, n);
+
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned r = 0; r < retries; ++r) {
+    if (mode == "gpu") {
+      if (parallel) {
+        for (unsigned j = 0; j < num_instances; ++j) { sp[j] = h_sc[j].data(); pp[j] = h_pts[j].data(); }
+        st = msm_amd_msm_batch(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, num_instances, sp.data(),
+                               pp.data(), ns.data(), out.data());
+        if (st) die(ctx, st, "msm_batch");
+      } else {
+        for (unsigned j = 0; j < num_instances; ++j) {   // sequential runs (gpu_profiler.rs:104-106)
+          st = msm_amd_gpu_msm_h2c(ctx, h_sc[j].data(), h_pts[j].data(), n, out.data() + (size_t)j * 96);
+          if (st) die(ctx, st, "gpu_msm_h2c");
+        }
+      }
+    } else {
+      for (unsigned j = 0; j < num_instances; ++j) { sp[j] = d_sc[j]; pp[j] = d_pts[j]; }
+      st = msm_amd_msm_batch_device(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, num_instances, sp.data(),
+                                    pp.data(), ns.data(), out.data());
+      if (st) die(ctx, st, "msm_batch_device");
+    }
+  }
+  const double total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  // the reference's two report lines (gpu_profiler.rs:135-140)
+  std::fprintf(stderr, "[INFO] Total Execution Time: %.3fms\n", total_ms);
+  std::fprintf(stderr, "[INFO] Average Instance Execution Time: %.3fms\n", total_ms / num_instances / retries);
+  msm_amd_timings t;
+  msm_amd_last_timings(ctx, &t);
+  if (json) {
+    std::printf("{\"log_size\": %u, \"num_instances\": %u, \"mode\": \"%s\", \"retries\": %u, \"total_ms\": %.4f, "
+                "\"avg_instance_ms\": %.4f, \"window_size\": %u, \"stage_ms\": {\"convert\": %.4f, \"digits\": %.4f, "
+                "\"sort\": %.4f, \"accumulate\": %.4f, \"reduce\": %.4f, \"host_final\": %.4f, \"gpu_total\": %.4f}, "
+                "\"result0_x_le_hex\": \"",
+                log_size, num_instances, mode.c_str(), retries, total_ms, total_ms / num_instances / retries,
+                t.window_size, t.convert_ms, t.digits_ms, t.sort_ms, t.accumulate_ms, t.reduce_ms, t.final_ms,
+                t.total_gpu_ms);
+    for (int i = 0; i < 32; ++i) std::printf("%02x", out[i]);
+    std::printf("\"}\n");
+  }
+  for (unsigned j = 0; j < num_instances; ++j) {
+    msm_amd_device_free(ctx, d_pts[j]);
+    msm_amd_device_free(ctx, d_sc[j]);
+  }
+  msm_amd_destroy(ctx);
+  return 0;
+}
