@@ -1,0 +1,205 @@
+// Pippenger MSM pipeline for BN254 G1 on gfx950 (MI355X): overview + helpers shared by the kernel TUs
+// (k_sort.hip, k_accumulate.hip, k_reduce.hip, k_misc.hip, k_stage.hip) and by the host driver.
+//
+// Pipeline (one MSM of n points, window c bits, W = ceil(254/c) windows, nb = 2^c digit values):
+//
+//   digits_kernel        scalars (32 B, Montgomery or canonical)  -> digits[W][n] (u16, SoA)
+//   hist_kernel          digits -> counts[W][Q][nb]     LDS histogram per (chunk q, window w)
+//   chunk_prefix_kernel  counts -> bucket_size[W][nb], counts := exclusive prefix over chunks
+//   scan_kernel          bucket_size -> bucket_start[W][nb]  (per-window exclusive scan in LDS)
+//   scatter_kernel       digits + cursors -> sorted[W][n]  (point indices grouped by digit)
+//   accumulate_kernel    sorted + bases(affine 64 B) -> buckets[W][nb]  (Jacobian 96 B)   <- dominant
+//   reduce_seg_kernel    buckets -> S[W][nseg], T[W][nseg]   (segments of 8 buckets)
+//   reduce_tree_kernel   S, T -> partial[W][K+1]  (one plain sum + K bit-subset sums per window)
+//   host                 Horner over bit positions of the (K+1)*W partial points
+//
+// This replaces the reference's prepare_buckets_indices / sort_buckets (CPU rayon sort!) /
+// bucket_wise_accumulation / sum_reduction_partial+final kernels (src/metal/shader/msm.h.metal:17-562,
+// src/metal/msm/sort_buckets.rs:15-34) with a design derived for wave64 + 160 KB LDS:
+//   * the sort is a per-window counting sort whose whole digit histogram (2^15 x u32 = 128 KB) lives in
+//     LDS, so ranking is LDS atomics and the only global traffic is digits in / indices out;
+//   * sorted output is 4 B point indices plus per-bucket offsets (the reference sorts 8 B pairs and
+//     then binary-searches bucket boundaries per threadgroup, msm.h.metal:61-73,130-131);
+//   * window sums use running sums over 8-bucket segments followed by bit-subset tree sums, which
+//     needs no scalar multiplications (the reference multiplies sums by counts with double-and-add in
+//     every combine, msm.h.metal:429-430).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bn254_ec.hip.h"
+#include "launch.h"
+
+namespace msm_amd {
+
+
+// ------------------------------------------------------------------------------------------------
+// 16-byte vector loads/stores of field elements and points (coalescing unit is 16 B/lane).
+__device__ __forceinline__ u256 load_u256(const void* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1];
+  u256 r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+  r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  return r;
+}
+
+__device__ __forceinline__ void store_u256(void* p, const u256& a) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+  q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+__device__ __forceinline__ Affine load_affine(const Affine* p) {
+  Affine r;
+  r.x = load_u256(&p->x);
+  r.y = load_u256(&p->y);
+  return r;
+}
+
+__device__ __forceinline__ void store_affine(Affine* p, const Affine& a) {
+  store_u256(&p->x, a.x);
+  store_u256(&p->y, a.y);
+}
+
+__device__ __forceinline__ Jacobian load_jac(const Jacobian* p) {
+  Jacobian r;
+  r.x = load_u256(&p->x);
+  r.y = load_u256(&p->y);
+  r.z = load_u256(&p->z);
+  return r;
+}
+
+__device__ __forceinline__ void store_jac(Jacobian* p, const Jacobian& a) {
+  store_u256(&p->x, a.x);
+  store_u256(&p->y, a.y);
+  store_u256(&p->z, a.z);
+}
+
+// Block-wide exclusive scan of one value per thread (blockDim.x <= 1024, multiple of 64).
+// Returns the exclusive prefix; *total receives the block sum.  scratch: >= 17 words of LDS.
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* scratch, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, 64);
+    if (lane >= (uint32_t)off) incl += up;
+  }
+  if (lane == 63) scratch[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t ws = lane < nwaves ? scratch[lane] : 0u;
+    uint32_t wi = ws;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const uint32_t up = __shfl_up(wi, off, 64);
+      if (lane >= (uint32_t)off) wi += up;
+    }
+    if (lane < nwaves) scratch[lane] = wi - ws;   // exclusive wave offsets
+    if (lane == nwaves - 1) scratch[16] = wi;     // block total
+  }
+  __syncthreads();
+  const uint32_t res = scratch[wave] + incl - v;
+  *total = scratch[16];
+  __syncthreads();
+  return res;
+}
+
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// Inversion / normalisation (host + device).
+MSM_HD u256 fq_inverse(const u256& a) {
+  // a^(p-2): exponent limbs of p - 2
+  u256 e = Fq::modulus();
+  e.v[0] -= 2u;   // p is odd and its low limb > 2
+  u256 r = Fq::one();
+  for (int i = 255; i >= 0; --i) {
+    r = Fq::sqr(r);
+    if ((e.v[i >> 5] >> (i & 31)) & 1u) r = Fq::mul(r, a);
+  }
+  return r;
+}
+
+MSM_HD Affine jac_to_affine(const Jacobian& p) {
+  Affine r;
+  if (jac_is_identity(p)) {
+    r.x = u256_zero();
+    r.y = u256_zero();
+    return r;
+  }
+  if (u256_eq(p.z, Fq::one())) {
+    r.x = p.x;
+    r.y = p.y;
+    return r;
+  }
+  const u256 zi = fq_inverse(p.z);
+  const u256 zi2 = Fq::sqr(zi);
+  r.x = Fq::mul(p.x, zi2);
+  r.y = Fq::mul(p.y, Fq::mul(zi2, zi));
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deterministic synthetic instance generator; bit-for-bit the generator of oracle/bn254_ref.py
+// (gen_point / gen_scalar) and oracle/msm_oracle.c.  Plays the role of the reference's random
+// instance generation (src/utils/preprocess.rs:113-138) for benchmarks and large parity tests.
+MSM_HD uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+MSM_HD uint64_t rnd64(uint64_t seed, uint64_t stream, uint64_t ctr) {
+  return splitmix64(splitmix64(seed ^ (stream << 56)) + ctr);
+}
+
+MSM_HD u256 rnd256(uint64_t seed, uint64_t stream, uint64_t ctr4) {
+  u256 r;
+  MSM_UNROLL for (int k = 0; k < 4; ++k) {
+    const uint64_t w = rnd64(seed, stream, ctr4 * 4 + k);
+    r.v[2 * k] = (uint32_t)w;
+    r.v[2 * k + 1] = (uint32_t)(w >> 32);
+  }
+  return r;
+}
+
+MSM_HD u256 fq_sqrt_candidate(const u256& a) {
+  // a^((p+1)/4), p = 3 mod 4.  (p+1)/4 little-endian limbs:
+  const uint32_t e[8] = {0xB61F3F52u, 0x4F082305u, 0x5A1C72A3u, 0x65E05AA4u,
+                         0xA0605617u, 0x6E14116Du, 0xB84C680Au, 0x0C19139Cu};
+  u256 r = Fq::one();
+  for (int i = 251; i >= 0; --i) {
+    r = Fq::sqr(r);
+    if ((e[i >> 5] >> (i & 31)) & 1u) r = Fq::mul(r, a);
+  }
+  return r;
+}
+
+// Returns false if this attempt does not yield a point.
+MSM_HD bool gen_point_attempt(uint64_t seed, uint64_t i, uint32_t attempt, Affine& out) {
+  u256 raw = rnd256(seed, 0, i * 64 + attempt);
+  const uint32_t sign = raw.v[7] >> 31;
+  raw.v[7] &= 0x3FFFFFFFu;                         // 254 bits
+  u256 d;
+  if (u256_sub(d, raw, Fq::modulus()) == 0) return false;   // x >= p
+  const u256 x = Fq::to_mont(raw);
+  u256 three = u256_zero();
+  three.v[0] = 3;
+  const u256 rhs = Fq::add(Fq::mul(Fq::sqr(x), x), Fq::to_mont(three));
+  u256 y = fq_sqrt_candidate(rhs);
+  if (!u256_eq(Fq::sqr(y), rhs)) return false;
+  if (sign) y = Fq::neg(y);
+  out.x = x;
+  out.y = y;
+  return true;
+}
+
+MSM_HD u256 gen_scalar_canonical(uint64_t seed, uint64_t i) {
+  u256 raw = rnd256(seed, 1, i);
+  raw.v[7] &= 0x3FFFFFFFu;
+  return Fr::reduce_once(raw);
+}
+
+}  // namespace msm_amd

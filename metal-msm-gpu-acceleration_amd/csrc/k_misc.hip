@@ -1,0 +1,44 @@
+// Conversion of projective inputs and the device-side synthetic instance generator.
+#include "device_common.hip.h"
+#include "launch.h"
+
+namespace msm_amd {
+
+// ark_bn254::G1Projective (x, y, z Montgomery LE, 96 B) -> affine 64 B.  One thread per point with a
+// Fermat inversion only when z is neither 0 nor one (the reference converts on the CPU, state.rs:88-109).
+__global__ void __launch_bounds__(64)
+projective_to_affine_kernel(const Jacobian* __restrict__ in, uint32_t n, Affine* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  store_affine(&out[t], jac_to_affine(load_jac(&in[t])));
+}
+
+// scalars_mont: write scalars in Montgomery form (what bn256::Fr / ark Fr hold in memory) or canonical.
+__global__ void __launch_bounds__(64)
+gen_instance_kernel(uint64_t seed, uint32_t n, int scalars_mont, Affine* __restrict__ bases,
+                    u256* __restrict__ scalars) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  Affine pt;
+  pt.x = u256_zero();
+  pt.y = u256_zero();
+#pragma unroll 1
+  for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+    if (gen_point_attempt(seed, t, attempt, pt)) break;
+  }
+  store_affine(&bases[t], pt);
+  u256 k = gen_scalar_canonical(seed, t);
+  if (scalars_mont) k = Fr::to_mont(k);
+  store_u256(&scalars[t], k);
+}
+
+
+void launch_projective_to_affine(hipStream_t st, const Jacobian* in, uint32_t n, Affine* out) {
+  hipLaunchKernelGGL(projective_to_affine_kernel, dim3((n + 63) / 64), dim3(64), 0, st, in, n, out);
+}
+
+void launch_gen_instance(hipStream_t st, uint64_t seed, uint32_t n, int scalars_mont, Affine* bases, u256* scalars) {
+  hipLaunchKernelGGL(gen_instance_kernel, dim3((n + 63) / 64), dim3(64), 0, st, seed, n, scalars_mont, bases, scalars);
+}
+
+}  // namespace msm_amd

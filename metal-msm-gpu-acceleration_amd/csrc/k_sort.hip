@@ -1,0 +1,329 @@
+// Sort-stage kernels: digit extraction, per-window LDS counting sort, work-item planning.
+// See device_common.hip.h for the pipeline overview.
+#include "device_common.hip.h"
+#include "launch.h"
+
+namespace msm_amd {
+
+constexpr int kSortThreads = 1024;       // hist / plan / scatter workgroup size
+
+// ------------------------------------------------------------------------------------------------
+// Stage 1: digit extraction.  Replaces kernel prepare_buckets_indices (msm.h.metal:17-59, one thread
+// per threadgroup and a generic 256-bit shift per window) and the CPU de-Montgomery of scalars
+// (limbs_conversion.rs:282-288).  scalars_mont: 1 = host Montgomery form (bn256::Fr / ark Fr memory),
+// 0 = canonical integer.
+__global__ void __launch_bounds__(256)
+digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W, int scalars_mont,
+              uint16_t* __restrict__ digits) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  u256 k = load_u256(&scalars[t]);
+  if (scalars_mont) k = Fr::from_mont(k);
+  for (uint32_t w = 0; w < W; ++w) {
+    const uint32_t d = u256_extract_bits(k, w * c, c);
+    digits[(size_t)w * n + t] = (uint16_t)d;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 2a: LDS histogram of one chunk of one window.  grid = (Q, W), block = kSortThreads,
+// dynamic LDS = nb * 4 bytes.
+__global__ void __launch_bounds__(kSortThreads)
+hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t c, uint32_t chunk,
+            uint32_t* __restrict__ counts) {
+  extern __shared__ uint32_t lds_u32[];
+  const uint32_t nb = 1u << c;
+  const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
+  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lds_u32[i] = 0;
+  __syncthreads();
+  const uint32_t lo = q * chunk;
+  const uint32_t hi = min(n, lo + chunk);
+  const uint16_t* dw = digits + (size_t)w * n;
+  for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
+    const uint32_t d = dw[t];
+    if (d) atomicAdd(&lds_u32[d], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = counts + ((size_t)w * Q + q) * nb;
+  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) out[i] = lds_u32[i];
+}
+
+// Stage 2b: per-bucket totals.  One thread per (window, digit): turns counts[w][q][d] into the exclusive
+// prefix over chunks q (position of chunk q's first element inside the bucket) and writes the bucket size.
+__global__ void __launch_bounds__(256)
+chunk_prefix_kernel(uint32_t* __restrict__ counts, uint32_t c, uint32_t Q, uint32_t W,
+                    uint32_t* __restrict__ bucket_size) {
+  const uint32_t nb = 1u << c;
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= W * nb) return;
+  const uint32_t w = b >> c, d = b & (nb - 1);
+  uint32_t* cw = counts + (size_t)w * Q * nb + d;
+  uint32_t run = 0;
+  for (uint32_t q = 0; q < Q; ++q) {
+    const uint32_t cnt = cw[(size_t)q * nb];
+    cw[(size_t)q * nb] = run;
+    run += cnt;
+  }
+  bucket_size[b] = run;
+}
+
+// Stage 2c: per-window planning.  grid = W, block = kSortThreads, dynamic LDS = (nb + nb/32 + 33) * 4 bytes.
+// Two exclusive scans over the window's buckets (one LDS array, used twice):
+//   bucket_start[w][d] = offset of bucket d inside the window's slice of `sorted`
+//   item_start[w][d]   = first work-item id of bucket d inside the window, where a bucket of s points
+//                        is cut into ceil(s / CH) items of at most CH points (empty buckets: none)
+// and win_items[w] = number of items of the window.
+__device__ __forceinline__ uint32_t window_scan_lds(uint32_t* tot, uint32_t* scratch, uint32_t nb) {
+  // in: tot[skew(d)] = value of bucket d ; out: tot[skew(d)] = exclusive prefix ; returns the total
+  const uint32_t per = (nb + blockDim.x - 1) / blockDim.x;   // consecutive entries per thread
+  const uint32_t first = threadIdx.x * per;
+  uint32_t local = 0;
+  for (uint32_t j = 0; j < per; ++j) {
+    const uint32_t d = first + j;
+    if (d < nb) local += tot[d + (d >> 5)];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(local, scratch, &total);
+  for (uint32_t j = 0; j < per; ++j) {
+    const uint32_t d = first + j;
+    if (d < nb) {
+      const uint32_t s = tot[d + (d >> 5)];
+      tot[d + (d >> 5)] = run;
+      run += s;
+    }
+  }
+  __syncthreads();
+  return total;
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+plan_kernel(const uint32_t* __restrict__ bucket_size, uint32_t c, uint32_t CH,
+            uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ item_start,
+            uint32_t* __restrict__ win_items) {
+  extern __shared__ uint32_t lds_u32[];
+  const uint32_t nb = 1u << c;
+  const uint32_t w = blockIdx.x;
+  uint32_t* tot = lds_u32;                               // skewed: index i lives at i + (i >> 5)
+  uint32_t* scratch = lds_u32 + nb + (nb >> 5) + 1;      // 17 words
+  const uint32_t* bsz = bucket_size + (size_t)w * nb;
+  for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) tot[d + (d >> 5)] = bsz[d];
+  __syncthreads();
+  window_scan_lds(tot, scratch, nb);
+  for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) bucket_start[(size_t)w * nb + d] = tot[d + (d >> 5)];
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) tot[d + (d >> 5)] = (bsz[d] + CH - 1) / CH;
+  __syncthreads();
+  const uint32_t total_items = window_scan_lds(tot, scratch, nb);
+  for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) item_start[(size_t)w * nb + d] = tot[d + (d >> 5)];
+  if (threadIdx.x == 0) win_items[w] = total_items;
+}
+
+// Stage 2d: scatter point indices to their bucket slots.  grid = (Q, W), dynamic LDS = nb * 4 bytes.
+// Order inside a bucket is unspecified (LDS atomic arrival order), exactly as the reference allows
+// (sort_buckets.rs:111-125 checks only multiset + non-decreasing keys).
+__global__ void __launch_bounds__(kSortThreads)
+scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t c, uint32_t chunk,
+               const uint32_t* __restrict__ chunk_prefix, const uint32_t* __restrict__ bucket_start,
+               uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t lds_u32[];
+  const uint32_t nb = 1u << c;
+  const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
+  const uint32_t* rel = chunk_prefix + ((size_t)w * Q + q) * nb;
+  const uint32_t* bs = bucket_start + (size_t)w * nb;
+  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lds_u32[i] = bs[i] + rel[i];
+  __syncthreads();
+  const uint32_t lo = q * chunk;
+  const uint32_t hi = min(n, lo + chunk);
+  const uint16_t* dw = digits + (size_t)w * n;
+  uint32_t* sw = sorted + (size_t)w * n;
+  for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
+    const uint32_t d = dw[t];
+    if (d) {
+      const uint32_t pos = atomicAdd(&lds_u32[d], 1u);
+      sw[pos] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Work-item ordering.  The accumulate kernel gives one lane to one work item (a bucket, or a CH-point
+// chunk of a large bucket).  Lanes of a wave finish together only if their items have the same length,
+// and the longest items must start first, so items are counting-sorted by DESCENDING size
+// (CH + 1 size classes).  Three small kernels over the buckets:
+//   size_hist_kernel     LDS histogram of item sizes per workgroup -> global size_bins
+//   size_scan_kernel     one workgroup: descending exclusive scan of size_bins (-> cursors), exclusive
+//                        scan of win_items (-> window base of item ids), total item count
+//   size_scatter_kernel  every bucket reserves its positions: one LDS-aggregated global atomic per
+//                        (workgroup, size class), LDS atomics inside the workgroup
+constexpr int kSizeThreads = 256;
+
+__device__ __forceinline__ void bucket_items(uint32_t s, uint32_t CH, uint32_t* nfull, uint32_t* last) {
+  // s points -> nfull items of CH points + (last ? one item of `last` points : none)
+  *nfull = s / CH;
+  *last = s - *nfull * CH;
+}
+
+__global__ void __launch_bounds__(kSizeThreads)
+size_hist_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_buckets, uint32_t CH,
+                 uint32_t* __restrict__ size_bins) {
+  extern __shared__ uint32_t lds_u32[];
+  for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x) lds_u32[i] = 0;
+  __syncthreads();
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < total_buckets) {
+    uint32_t nfull, last;
+    bucket_items(bucket_size[b], CH, &nfull, &last);
+    if (nfull) atomicAdd(&lds_u32[CH], nfull);
+    if (last) atomicAdd(&lds_u32[last], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x) {
+    const uint32_t v = lds_u32[i];
+    if (v) atomicAdd(&size_bins[i], v);
+  }
+}
+
+// One workgroup of 1024 threads.  CH <= 1024, W <= 1024.
+__global__ void __launch_bounds__(1024)
+size_scan_kernel(uint32_t* __restrict__ size_bins, uint32_t CH, uint32_t* __restrict__ win_items, uint32_t W,
+                 PlanCounters* __restrict__ counters) {
+  __shared__ uint32_t scratch[17];
+  // descending order: thread t owns size class CH - t
+  const uint32_t t = threadIdx.x;
+  uint32_t v = (t <= CH) ? size_bins[CH - t] : 0u;
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan(v, scratch, &total);
+  if (t <= CH) size_bins[CH - t] = ex;
+  if (t == 0) {
+    counters->total_items = total;
+    counters->multi_count = 0;
+  }
+  uint32_t wv = (t < W) ? win_items[t] : 0u;
+  uint32_t wtotal;
+  uint32_t wex = block_exclusive_scan(wv, scratch, &wtotal);
+  if (t < W) win_items[t] = wex;
+}
+
+__global__ void __launch_bounds__(kSizeThreads)
+size_scatter_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_buckets, uint32_t CH,
+                    uint32_t* __restrict__ size_cursor, uint2* __restrict__ order,
+                    uint32_t* __restrict__ multi_list, PlanCounters* __restrict__ counters) {
+  extern __shared__ uint32_t lds_u32[];
+  uint32_t* cnt = lds_u32;              // [CH + 1] local counts, then local ranks
+  uint32_t* base = lds_u32 + CH + 1;    // [CH + 1] reserved global base per size class
+  for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t nfull = 0, last = 0;
+  if (b < total_buckets) {
+    bucket_items(bucket_size[b], CH, &nfull, &last);
+    if (nfull) atomicAdd(&cnt[CH], nfull);
+    if (last) atomicAdd(&cnt[last], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x) {
+    const uint32_t v = cnt[i];
+    base[i] = v ? atomicAdd(&size_cursor[i], v) : 0u;
+    cnt[i] = 0;
+  }
+  __syncthreads();
+  if (b < total_buckets) {
+    if (nfull) {
+      const uint32_t pos = base[CH] + atomicAdd(&cnt[CH], nfull);
+      for (uint32_t j = 0; j < nfull; ++j) order[pos + j] = make_uint2(b, j);
+    }
+    if (last) {
+      const uint32_t pos = base[last] + atomicAdd(&cnt[last], 1u);
+      order[pos] = make_uint2(b, nfull);
+    }
+    if (nfull + (last ? 1u : 0u) > 1u) {
+      const uint32_t slot = atomicAdd(&counters->multi_count, 1u);
+      multi_list[slot] = b;
+    }
+  }
+}
+
+// ark_bn254::G1Affine {x: Fq, y: Fq, infinity: bool} = 72 bytes (8-byte aligned).
+__global__ void __launch_bounds__(256)
+ark_affine_to_affine_kernel(const uint8_t* __restrict__ in, uint32_t n, Affine* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(in + (size_t)t * 72);
+  Affine a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a.x.v[i] = src[i];
+    a.y.v[i] = src[8 + i];
+  }
+  if (src[16] & 0xFFu) {
+    a.x = u256_zero();
+    a.y = u256_zero();
+  }
+  store_affine(&out[t], a);
+}
+
+// Reference wire layout (8 x u32, most significant limb first) -> little-endian.
+// words = number of 256-bit values.
+__global__ void __launch_bounds__(256)
+be32_to_le_kernel(const uint32_t* __restrict__ in, size_t words, uint32_t* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= words * 8) return;
+  const size_t e = t >> 3;
+  const uint32_t l = (uint32_t)(t & 7);
+  out[e * 8 + l] = in[e * 8 + (7 - l)];
+}
+
+
+// ------------------------------------------------------------------------------------------------
+static size_t lds_hist_bytes(uint32_t c) { return (size_t)(1u << c) * 4; }
+static size_t lds_plan_bytes(uint32_t c) { return ((size_t)(1u << c) + ((1u << c) >> 5) + 33) * 4; }
+
+int sort_set_attributes(const char** failed) {
+  const int max_lds = 160 * 1024;
+  struct { const void* fn; const char* name; } ks[] = {{(const void*)hist_kernel, "hist_kernel"},
+                                                        {(const void*)plan_kernel, "plan_kernel"},
+                                                        {(const void*)scatter_kernel, "scatter_kernel"}};
+  for (auto& k : ks) {
+    if (hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess) {
+      (void)hipGetLastError();
+      *failed = k.name;
+      return 1;
+    }
+  }
+  return 0;
+}
+
+void launch_digits(hipStream_t st, const Plan& p, const u256* scalars, int scalars_mont, uint16_t* digits) {
+  hipLaunchKernelGGL(digits_kernel, dim3((p.n + 255) / 256), dim3(256), 0, st, scalars, p.n, p.c, p.W, scalars_mont,
+                     digits);
+}
+
+void launch_sort(hipStream_t st, const Plan& p, const SortBuffers& b) {
+  hipLaunchKernelGGL(hist_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.c), st,
+                     (const uint16_t*)b.digits, p.n, p.c, p.chunk, b.counts);
+  hipLaunchKernelGGL(chunk_prefix_kernel, dim3((unsigned)((p.total_buckets + 255) / 256)), dim3(256), 0, st,
+                     b.counts, p.c, p.Q, p.W, b.bucket_size);
+  hipLaunchKernelGGL(plan_kernel, dim3(p.W), dim3(kSortThreads), lds_plan_bytes(p.c), st,
+                     (const uint32_t*)b.bucket_size, p.c, p.CH, b.bucket_start, b.item_start, b.win_items);
+  hipLaunchKernelGGL(scatter_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.c), st,
+                     (const uint16_t*)b.digits, p.n, p.c, p.chunk, (const uint32_t*)b.counts,
+                     (const uint32_t*)b.bucket_start, b.sorted);
+  (void)hipMemsetAsync(b.size_bins, 0, (p.CH + 1) * sizeof(uint32_t), st);
+  const unsigned gb = (unsigned)((p.total_buckets + kSizeThreads - 1) / kSizeThreads);
+  hipLaunchKernelGGL(size_hist_kernel, dim3(gb), dim3(kSizeThreads), (p.CH + 1) * 4, st,
+                     (const uint32_t*)b.bucket_size, (uint32_t)p.total_buckets, p.CH, b.size_bins);
+  hipLaunchKernelGGL(size_scan_kernel, dim3(1), dim3(1024), 0, st, b.size_bins, p.CH, b.win_items, p.W, b.counters);
+  hipLaunchKernelGGL(size_scatter_kernel, dim3(gb), dim3(kSizeThreads), 2 * (p.CH + 1) * 4, st,
+                     (const uint32_t*)b.bucket_size, (uint32_t)p.total_buckets, p.CH, b.size_bins, b.order,
+                     b.multi_list, b.counters);
+}
+
+void launch_be32_to_le(hipStream_t st, const uint32_t* in, size_t words, uint32_t* out) {
+  hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)((words * 8 + 255) / 256)), dim3(256), 0, st, in, words, out);
+}
+
+void launch_ark_affine_to_affine(hipStream_t st, const uint8_t* in, uint32_t n, Affine* out) {
+  hipLaunchKernelGGL(ark_affine_to_affine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, in, n, out);
+}
+
+}  // namespace msm_amd

@@ -1,5 +1,5 @@
 // Kernels behind the per-stage C-ABI entry points (reference wire semantics) and the single-op test
-// kernels.  Included by msm_host.hip.
+// kernels.  Launched through launch.h.
 //
 //   ref_prepare_kernel      == kernel prepare_buckets_indices (msm.h.metal:17-59) output format
 //   radix_*_kernel          stand-alone device sort of (u32 key, u32 value) pairs: the stage the
@@ -8,10 +8,11 @@
 //   ref_accumulate_kernel   == kernel bucket_wise_accumulation (msm.h.metal:75-315) on Jacobian inputs
 //   pad_buckets_kernel      feeds the production window reduction from a reference-layout bucket matrix
 //   test_op_kernel          == the 12 single-thread test kernels of shader/tests/*.h.metal, batched
-#pragma once
-#include "msm_kernels.hip.h"
+#include "device_common.hip.h"
+#include "launch.h"
 
 namespace msm_amd {
+
 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -39,8 +40,6 @@ ref_prepare_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uin
 // ------------------------------------------------------------------------------------------------
 // LSD radix sort, one pass = hist + scan + scatter.  Tile = 256 threads x kRadixItems items; each
 // wave owns a contiguous quarter of the tile so that wave order == memory order (stability).
-constexpr int kRadixItems = 16;
-constexpr int kRadixTile = 256 * kRadixItems;
 
 __global__ void __launch_bounds__(256)
 radix_hist_kernel(const uint2* __restrict__ in, size_t n, uint32_t shift, uint32_t num_tiles,
@@ -207,6 +206,46 @@ test_op_kernel(int op, const u256* __restrict__ a, const u256* __restrict__ b, u
     r = jac_double(p);
   }
   store_jac(reinterpret_cast<Jacobian*>(out) + t, r);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+void launch_ref_prepare(hipStream_t st, const u256* scalars, uint32_t n, uint32_t c, uint32_t W, uint2* pairs) {
+  hipLaunchKernelGGL(ref_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, st, scalars, n, c, W, pairs);
+}
+
+// Sorts n pairs by key; a and b are ping-pong buffers of n pairs, tile_hist holds 256 * tiles words.
+// *result points to whichever buffer holds the sorted output.
+void launch_radix_sort_pairs(hipStream_t st, uint2* a, uint2* b, size_t n, uint32_t* tile_hist, uint2** result) {
+  const uint32_t tiles = (uint32_t)((n + kRadixTile - 1) / kRadixTile);
+  uint2* src = a;
+  uint2* dst = b;
+  for (uint32_t shift = 0; shift < 32; shift += 8) {
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(256), 0, st, (const uint2*)src, n, shift, tiles,
+                       tile_hist);
+    hipLaunchKernelGGL(linear_scan_kernel, dim3(1), dim3(1024), 0, st, tile_hist, (size_t)tiles * 256);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(256), 0, st, (const uint2*)src, dst, n, shift, tiles,
+                       (const uint32_t*)tile_hist);
+    uint2* t = src;
+    src = dst;
+    dst = t;
+  }
+  *result = src;
+}
+
+void launch_ref_accumulate(hipStream_t st, const uint2* pairs, size_t n_pairs, const Jacobian* points,
+                           uint32_t n_points, uint32_t total_buckets, Jacobian* buckets) {
+  hipLaunchKernelGGL(ref_accumulate_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st, pairs, n_pairs,
+                     points, n_points, total_buckets, buckets);
+}
+
+void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t c, Jacobian* out) {
+  const size_t total = (size_t)W << c;
+  hipLaunchKernelGGL(pad_buckets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, bs, W, c, out);
+}
+
+void launch_test_op(hipStream_t st, int op, const u256* a, const u256* b, u256* out, uint32_t count) {
+  hipLaunchKernelGGL(test_op_kernel, dim3((count + 63) / 64), dim3(64), 0, st, op, a, b, out, count);
 }
 
 }  // namespace msm_amd

@@ -1,0 +1,76 @@
+// Launch wrappers exported by the kernel translation units (k_*.hip) to the host driver (msm_host.hip).
+// Every wrapper only enqueues work on `st`; none synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "bn254_ec.hip.h"
+
+namespace msm_amd {
+
+constexpr int kSegLog = 3;   // window reduction: segments of 2^3 buckets
+constexpr int kSeg = 1 << kSegLog;
+
+// Geometry of one MSM (see make_plan in msm_host.hip).
+struct Plan {
+  uint32_t n, c, W, nb;       // points, window bits, windows, digit values per window (2^c)
+  uint32_t Q, chunk;          // sort: chunks per window, points per chunk
+  uint32_t CH;                // accumulate: max points per work item (bucket chunk)
+  uint32_t nseg, K;           // reduce: segments per window, bits of segment index (c - 3)
+  uint32_t tree_threads;
+  size_t total_buckets, total_segs, partial_count, max_items;
+};
+
+// Device-side bookkeeping words written by the planning kernels.
+struct PlanCounters {
+  uint32_t total_items;       // number of accumulate work items
+  uint32_t multi_count;       // number of buckets split into more than one item
+  uint32_t pad[2];
+};
+
+struct SortBuffers {
+  uint16_t* digits;           // [W][n]
+  uint32_t* counts;           // [W][Q][nb]
+  uint32_t* bucket_size;      // [W][nb]
+  uint32_t* bucket_start;     // [W][nb]   offset inside the window's slice of `sorted`
+  uint32_t* item_start;       // [W][nb]   first item id of the bucket inside its window
+  uint32_t* win_items;        // [W]       items per window, then exclusive prefix (window base)
+  uint32_t* size_bins;        // [CH + 1]  item-size histogram, then write cursors
+  uint32_t* sorted;           // [W][n]
+  uint2* order;               // [max_items] (bucket, chunk) by descending size
+  uint32_t* multi_list;       // [max_items] buckets with more than one item
+  PlanCounters* counters;
+};
+
+// k_sort.hip
+int sort_set_attributes(const char** failed);
+void launch_digits(hipStream_t st, const Plan& p, const u256* scalars, int scalars_mont, uint16_t* digits);
+void launch_sort(hipStream_t st, const Plan& p, const SortBuffers& b);
+void launch_be32_to_le(hipStream_t st, const uint32_t* in, size_t words, uint32_t* out);
+void launch_ark_affine_to_affine(hipStream_t st, const uint8_t* in, uint32_t n, Affine* out);
+
+// k_accumulate.hip
+void launch_accumulate(hipStream_t st, const Plan& p, const Affine* bases, const SortBuffers& b, Jacobian* buckets,
+                       Jacobian* partials);
+
+// k_reduce.hip
+int reduce_set_attributes(const char** failed);
+void launch_reduce(hipStream_t st, const Plan& p, const Jacobian* buckets, Jacobian* S, Jacobian* T,
+                   Jacobian* partial);
+
+// k_misc.hip
+void launch_projective_to_affine(hipStream_t st, const Jacobian* in, uint32_t n, Affine* out);
+void launch_gen_instance(hipStream_t st, uint64_t seed, uint32_t n, int scalars_mont, Affine* bases, u256* scalars);
+
+// k_stage.hip
+constexpr int kRadixItems = 16;
+constexpr int kRadixTile = 256 * kRadixItems;
+void launch_ref_prepare(hipStream_t st, const u256* scalars, uint32_t n, uint32_t c, uint32_t W, uint2* pairs);
+void launch_radix_sort_pairs(hipStream_t st, uint2* a, uint2* b, size_t n, uint32_t* tile_hist, uint2** result);
+void launch_ref_accumulate(hipStream_t st, const uint2* pairs, size_t n_pairs, const Jacobian* points,
+                           uint32_t n_points, uint32_t total_buckets, Jacobian* buckets);
+void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t c, Jacobian* out);
+void launch_test_op(hipStream_t st, int op, const u256* a, const u256* b, u256* out, uint32_t count);
+
+}  // namespace msm_amd

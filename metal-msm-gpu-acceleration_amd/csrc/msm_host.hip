@@ -17,7 +17,8 @@
 #include <vector>
 
 #include "../../include/msm_amd.h"
-#include "stage_kernels.hip.h"
+#include "device_common.hip.h"
+#include "launch.h"
 
 using namespace msm_amd;
 
@@ -29,11 +30,6 @@ constexpr uint32_t kMinWindow = 3, kMaxWindow = 15;
 struct DeviceBuf {
   void* p = nullptr;
   size_t cap = 0;
-};
-
-struct Plan {
-  uint32_t n, c, W, nb, Q, chunk, nseg, K, tree_threads;
-  size_t total_buckets, total_segs, partial_count;
 };
 
 enum { EV_START = 0, EV_CONVERT, EV_DIGITS, EV_SORT, EV_ACC, EV_REDUCE, EV_COUNT };
@@ -53,8 +49,8 @@ struct msm_amd_ctx {
   std::mutex mu;
   std::string last_error;
   uint32_t forced_window = 0;
-  DeviceBuf digits, counts, bsize, bstart, sorted, buckets, S, T, partial, conv_scalars, conv_points, scratch_a,
-      scratch_b, scratch_c;
+  DeviceBuf digits, counts, bsize, bstart, istart, win_items, size_bins, sorted, order, multi_list, counters,
+      buckets, item_partials, S, T, partial, conv_scalars, conv_points, scratch_a, scratch_b, scratch_c;
   std::vector<InstanceSlot> slots;
   msm_amd_timings timings{};
 };
@@ -117,6 +113,30 @@ Plan make_plan(size_t n, uint32_t c) {
   Q = std::max(1u, std::min(Q, max_q));
   p.Q = Q;
   p.chunk = (uint32_t)((n + Q - 1) / Q);
+  // accumulate work items: at most CH points each; CH = 4 x the mean bucket population (so that
+  // uniformly distributed digits never split a bucket), power of two, 64..512
+  uint32_t ch = 64;
+  const size_t mean = std::max<size_t>(1, n >> c);
+  while (ch < 512 && ch < 4 * mean) ch <<= 1;
+  p.CH = ch;
+  p.nseg = p.nb >> kSegLog;
+  p.K = c - kSegLog;
+  p.total_buckets = (size_t)p.W * p.nb;
+  p.total_segs = (size_t)p.W * p.nseg;
+  p.partial_count = (size_t)p.W * (p.K + 1);
+  p.max_items = p.total_buckets + ((size_t)p.W * n) / ch + 1;
+  uint32_t t = 64;
+  while (t < 1024 && t < std::max(1u, p.nseg / 2)) t <<= 1;
+  p.tree_threads = t;
+  return p;
+}
+
+// Geometry of the window reduction alone (stage entry point sum_reduction).
+Plan make_reduce_plan(uint32_t c, uint32_t W) {
+  Plan p{};
+  p.c = c;
+  p.W = W;
+  p.nb = 1u << c;
   p.nseg = p.nb >> kSegLog;
   p.K = c - kSegLog;
   p.total_buckets = (size_t)p.W * p.nb;
@@ -127,9 +147,6 @@ Plan make_plan(size_t n, uint32_t c) {
   p.tree_threads = t;
   return p;
 }
-
-size_t lds_hist_bytes(uint32_t c) { return (size_t)(1u << c) * 4; }
-size_t lds_scan_bytes(uint32_t c) { return ((size_t)(1u << c) + ((1u << c) >> 5) + 32) * 4; }
 
 // ---- host-side big-endian-limb helpers (reference wire layout) ----------------------------------
 u256 be32_to_u256(const uint32_t* l) {
@@ -184,22 +201,9 @@ Jacobian host_combine(const Jacobian* partial, const Plan& p) {
 }
 
 int set_kernel_attributes(msm_amd_ctx* ctx) {
-  const int max_lds = 160 * 1024;
-  struct {
-    const void* fn;
-    const char* name;
-  } ks[] = {{(const void*)hist_kernel, "hist_kernel"},
-            {(const void*)scan_kernel, "scan_kernel"},
-            {(const void*)scatter_kernel, "scatter_kernel"},
-            {(const void*)reduce_tree_kernel, "reduce_tree_kernel"}};
-  for (auto& k : ks) {
-    hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      return fail(ctx, MSM_AMD_FUNCTION_ERROR,
-                  std::string("hipFuncSetAttribute(") + k.name + "): " + hipGetErrorString(e));
-    }
-  }
+  const char* failed = nullptr;
+  if (sort_set_attributes(&failed) || reduce_set_attributes(&failed))
+    return fail(ctx, MSM_AMD_FUNCTION_ERROR, std::string("hipFuncSetAttribute(") + (failed ? failed : "?") + ")");
   return MSM_AMD_OK;
 }
 
@@ -235,9 +239,7 @@ int convert_inputs(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const 
     case MSM_AMD_SCALAR_CANON_BE32: {
       int rc = ensure(ctx, ctx->conv_scalars, n * 32);
       if (rc) return rc;
-      const size_t words = n;
-      hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)((words * 8 + 255) / 256)), dim3(256), 0, st,
-                         (const uint32_t*)d_scalars, words, (uint32_t*)ctx->conv_scalars.p);
+      launch_be32_to_le(st, (const uint32_t*)d_scalars, n, (uint32_t*)ctx->conv_scalars.p);
       *scalars_native = (const u256*)ctx->conv_scalars.p;
       *scalars_mont = 0;
       break;
@@ -252,16 +254,14 @@ int convert_inputs(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const 
     case MSM_AMD_POINT_ARK_PROJECTIVE: {
       int rc = ensure(ctx, ctx->conv_points, n * sizeof(Affine));
       if (rc) return rc;
-      hipLaunchKernelGGL(projective_to_affine_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st,
-                         (const Jacobian*)d_points, (uint32_t)n, (Affine*)ctx->conv_points.p);
+      launch_projective_to_affine(st, (const Jacobian*)d_points, (uint32_t)n, (Affine*)ctx->conv_points.p);
       *points_native = (const Affine*)ctx->conv_points.p;
       break;
     }
     case MSM_AMD_POINT_ARK_AFFINE: {
       int rc = ensure(ctx, ctx->conv_points, n * sizeof(Affine));
       if (rc) return rc;
-      hipLaunchKernelGGL(ark_affine_to_affine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                         (const uint8_t*)d_points, (uint32_t)n, (Affine*)ctx->conv_points.p);
+      launch_ark_affine_to_affine(st, (const uint8_t*)d_points, (uint32_t)n, (Affine*)ctx->conv_points.p);
       *points_native = (const Affine*)ctx->conv_points.p;
       break;
     }
@@ -270,11 +270,8 @@ int convert_inputs(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const 
       if (rc) return rc;
       rc = ensure(ctx, ctx->conv_points, n * sizeof(Affine));
       if (rc) return rc;
-      const size_t words = n * 3;
-      hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)((words * 8 + 255) / 256)), dim3(256), 0, st,
-                         (const uint32_t*)d_points, words, (uint32_t*)ctx->scratch_a.p);
-      hipLaunchKernelGGL(projective_to_affine_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st,
-                         (const Jacobian*)ctx->scratch_a.p, (uint32_t)n, (Affine*)ctx->conv_points.p);
+      launch_be32_to_le(st, (const uint32_t*)d_points, n * 3, (uint32_t*)ctx->scratch_a.p);
+      launch_projective_to_affine(st, (const Jacobian*)ctx->scratch_a.p, (uint32_t)n, (Affine*)ctx->conv_points.p);
       *points_native = (const Affine*)ctx->conv_points.p;
       break;
     }
@@ -303,11 +300,7 @@ int enqueue_reduce(msm_amd_ctx* ctx, const Plan& p, const Jacobian* buckets) {
   if ((rc = ensure(ctx, ctx->S, p.total_segs * sizeof(Jacobian)))) return rc;
   if ((rc = ensure(ctx, ctx->T, p.total_segs * sizeof(Jacobian)))) return rc;
   if ((rc = ensure(ctx, ctx->partial, p.partial_count * sizeof(Jacobian)))) return rc;
-  hipLaunchKernelGGL(reduce_seg_kernel, dim3((unsigned)((p.total_segs + 63) / 64)), dim3(64), 0, st, buckets,
-                     (uint32_t)p.total_segs, (Jacobian*)ctx->S.p, (Jacobian*)ctx->T.p);
-  hipLaunchKernelGGL(reduce_tree_kernel, dim3(p.K + 1, p.W), dim3(p.tree_threads),
-                     p.tree_threads * sizeof(Jacobian), st, (const Jacobian*)ctx->S.p, (const Jacobian*)ctx->T.p,
-                     p.nseg, p.K, (Jacobian*)ctx->partial.p);
+  launch_reduce(st, p, buckets, (Jacobian*)ctx->S.p, (Jacobian*)ctx->T.p, (Jacobian*)ctx->partial.p);
   HIP_TRY(ctx, hipGetLastError());
   return MSM_AMD_OK;
 }
@@ -325,8 +318,27 @@ int enqueue_msm(msm_amd_ctx* ctx, InstanceSlot& slot, int scalar_layout, int poi
   if ((rc = ensure(ctx, ctx->counts, (size_t)p.W * p.Q * p.nb * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, ctx->bsize, p.total_buckets * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, ctx->bstart, p.total_buckets * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->istart, p.total_buckets * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->win_items, 1024 * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->size_bins, 1025 * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, ctx->sorted, (size_t)p.W * n * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->order, p.max_items * sizeof(uint2)))) return rc;
+  if ((rc = ensure(ctx, ctx->multi_list, p.max_items * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->counters, sizeof(PlanCounters)))) return rc;
   if ((rc = ensure(ctx, ctx->buckets, p.total_buckets * sizeof(Jacobian)))) return rc;
+  if ((rc = ensure(ctx, ctx->item_partials, p.max_items * sizeof(Jacobian)))) return rc;
+  SortBuffers sb{};
+  sb.digits = (uint16_t*)ctx->digits.p;
+  sb.counts = (uint32_t*)ctx->counts.p;
+  sb.bucket_size = (uint32_t*)ctx->bsize.p;
+  sb.bucket_start = (uint32_t*)ctx->bstart.p;
+  sb.item_start = (uint32_t*)ctx->istart.p;
+  sb.win_items = (uint32_t*)ctx->win_items.p;
+  sb.size_bins = (uint32_t*)ctx->size_bins.p;
+  sb.sorted = (uint32_t*)ctx->sorted.p;
+  sb.order = (uint2*)ctx->order.p;
+  sb.multi_list = (uint32_t*)ctx->multi_list.p;
+  sb.counters = (PlanCounters*)ctx->counters.p;
 
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_START], st));
   const u256* sc = nullptr;
@@ -335,24 +347,13 @@ int enqueue_msm(msm_amd_ctx* ctx, InstanceSlot& slot, int scalar_layout, int poi
   if ((rc = convert_inputs(ctx, scalar_layout, point_layout, d_scalars, d_points, n, &sc, &sc_mont, &pts))) return rc;
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_CONVERT], st));
 
-  hipLaunchKernelGGL(digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc, p.n, p.c, p.W, sc_mont,
-                     (uint16_t*)ctx->digits.p);
+  launch_digits(st, p, sc, sc_mont, sb.digits);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_DIGITS], st));
 
-  hipLaunchKernelGGL(hist_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.c), st,
-                     (const uint16_t*)ctx->digits.p, p.n, p.c, p.chunk, (uint32_t*)ctx->counts.p);
-  hipLaunchKernelGGL(chunk_prefix_kernel, dim3((unsigned)((p.total_buckets + 255) / 256)), dim3(256), 0, st,
-                     (uint32_t*)ctx->counts.p, p.c, p.Q, p.W, (uint32_t*)ctx->bsize.p);
-  hipLaunchKernelGGL(scan_kernel, dim3(p.W), dim3(kSortThreads), lds_scan_bytes(p.c), st,
-                     (const uint32_t*)ctx->bsize.p, p.c, (uint32_t*)ctx->bstart.p);
-  hipLaunchKernelGGL(scatter_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.c), st,
-                     (const uint16_t*)ctx->digits.p, p.n, p.c, p.chunk, (const uint32_t*)ctx->counts.p,
-                     (const uint32_t*)ctx->bstart.p, (uint32_t*)ctx->sorted.p);
+  launch_sort(st, p, sb);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_SORT], st));
 
-  hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((p.total_buckets + 63) / 64)), dim3(64), 0, st, pts,
-                     (const uint32_t*)ctx->sorted.p, (const uint32_t*)ctx->bstart.p, (const uint32_t*)ctx->bsize.p,
-                     (const uint32_t*)nullptr, p.n, p.c, (uint32_t)p.total_buckets, (Jacobian*)ctx->buckets.p);
+  launch_accumulate(st, p, pts, sb, (Jacobian*)ctx->buckets.p, (Jacobian*)ctx->item_partials.p);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
 
   if ((rc = enqueue_reduce(ctx, p, (const Jacobian*)ctx->buckets.p))) return rc;
@@ -547,9 +548,10 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  DeviceBuf* bufs[] = {&ctx->digits, &ctx->counts, &ctx->bsize, &ctx->bstart, &ctx->sorted, &ctx->buckets, &ctx->S,
-                       &ctx->T, &ctx->partial, &ctx->conv_scalars, &ctx->conv_points, &ctx->scratch_a,
-                       &ctx->scratch_b, &ctx->scratch_c};
+  DeviceBuf* bufs[] = {&ctx->digits, &ctx->counts, &ctx->bsize, &ctx->bstart, &ctx->istart, &ctx->win_items,
+                       &ctx->size_bins, &ctx->sorted, &ctx->order, &ctx->multi_list, &ctx->counters, &ctx->buckets,
+                       &ctx->item_partials, &ctx->S, &ctx->T, &ctx->partial, &ctx->conv_scalars, &ctx->conv_points,
+                       &ctx->scratch_a, &ctx->scratch_b, &ctx->scratch_c};
   for (DeviceBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (InstanceSlot& s : ctx->slots) {
@@ -656,8 +658,7 @@ int msm_amd_generate_instance(msm_amd_ctx* ctx, uint64_t seed, size_t n, int sca
     return fail(ctx, MSM_AMD_INPUT_ERROR, "bad generate_instance arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(gen_instance_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, seed,
-                     (uint32_t)n, scalars_mont, (Affine*)d_points, (u256*)d_scalars);
+  launch_gen_instance(ctx->stream, seed, (uint32_t)n, scalars_mont, (Affine*)d_points, (u256*)d_scalars);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MSM_AMD_OK;
@@ -677,10 +678,9 @@ int msm_amd_prepare_buckets_indices(msm_amd_ctx* ctx, const uint32_t* scalars_be
   if ((rc = ensure(ctx, ctx->scratch_b, n * 32))) return rc;
   if ((rc = ensure(ctx, ctx->scratch_c, pair_bytes))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, scalars_be32, n * 32, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st,
-                     (const uint32_t*)ctx->scratch_a.p, n, (uint32_t*)ctx->scratch_b.p);
-  hipLaunchKernelGGL(ref_prepare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                     (const u256*)ctx->scratch_b.p, (uint32_t)n, window_size, num_windows, (uint2*)ctx->scratch_c.p);
+  launch_be32_to_le(st, (const uint32_t*)ctx->scratch_a.p, n, (uint32_t*)ctx->scratch_b.p);
+  launch_ref_prepare(st, (const u256*)ctx->scratch_b.p, (uint32_t)n, window_size, num_windows,
+                     (uint2*)ctx->scratch_c.p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(pairs_out, ctx->scratch_c.p, pair_bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -700,17 +700,9 @@ int msm_amd_sort_buckets_indices(msm_amd_ctx* ctx, uint32_t* pairs, size_t n_pai
   if ((rc = ensure(ctx, ctx->scratch_b, n_pairs * 8))) return rc;
   if ((rc = ensure(ctx, ctx->scratch_c, (size_t)tiles * 256 * 4))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, pairs, n_pairs * 8, hipMemcpyHostToDevice, st));
-  uint2* src = (uint2*)ctx->scratch_a.p;
-  uint2* dst = (uint2*)ctx->scratch_b.p;
-  for (uint32_t shift = 0; shift < 32; shift += 8) {
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(256), 0, st, (const uint2*)src, n_pairs, shift, tiles,
-                       (uint32_t*)ctx->scratch_c.p);
-    hipLaunchKernelGGL(linear_scan_kernel, dim3(1), dim3(1024), 0, st, (uint32_t*)ctx->scratch_c.p,
-                       (size_t)tiles * 256);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(256), 0, st, (const uint2*)src, dst, n_pairs, shift,
-                       tiles, (const uint32_t*)ctx->scratch_c.p);
-    std::swap(src, dst);
-  }
+  uint2* src = nullptr;
+  launch_radix_sort_pairs(st, (uint2*)ctx->scratch_a.p, (uint2*)ctx->scratch_b.p, n_pairs,
+                          (uint32_t*)ctx->scratch_c.p, &src);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(pairs, src, n_pairs * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -732,18 +724,15 @@ int msm_amd_bucket_wise_accumulation(msm_amd_ctx* ctx, const uint32_t* sorted_pa
   if ((rc = ensure(ctx, ctx->scratch_c, std::max<size_t>(n_pairs * 8, 8)))) return rc;
   if ((rc = ensure(ctx, ctx->buckets, bkt_bytes))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, points_be32, pts_bytes, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)((n_points * 24 + 255) / 256)), dim3(256), 0, st,
-                     (const uint32_t*)ctx->scratch_a.p, n_points * 3, (uint32_t*)ctx->scratch_b.p);
+  launch_be32_to_le(st, (const uint32_t*)ctx->scratch_a.p, n_points * 3, (uint32_t*)ctx->scratch_b.p);
   HIP_TRY(ctx, hipMemsetAsync(ctx->buckets.p, 0, bkt_bytes, st));   // Appendix B item 8: explicit zero fill
   if (n_pairs) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, sorted_pairs, n_pairs * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(ref_accumulate_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, st,
-                       (const uint2*)ctx->scratch_c.p, n_pairs, (const Jacobian*)ctx->scratch_b.p,
-                       (uint32_t)n_points, total_buckets, (Jacobian*)ctx->buckets.p);
+    launch_ref_accumulate(st, (const uint2*)ctx->scratch_c.p, n_pairs, (const Jacobian*)ctx->scratch_b.p,
+                          (uint32_t)n_points, total_buckets, (Jacobian*)ctx->buckets.p);
   }
   // LE -> BE32 is the same limb reversal
-  hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)(((size_t)total_buckets * 24 + 255) / 256)), dim3(256), 0, st,
-                     (const uint32_t*)ctx->buckets.p, (size_t)total_buckets * 3, (uint32_t*)ctx->scratch_a.p);
+  launch_be32_to_le(st, (const uint32_t*)ctx->buckets.p, (size_t)total_buckets * 3, (uint32_t*)ctx->scratch_a.p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(buckets_out, ctx->scratch_a.p, bkt_bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -761,18 +750,7 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  Plan p{};
-  p.c = c;
-  p.W = num_windows;
-  p.nb = 1u << c;
-  p.nseg = p.nb >> kSegLog;
-  p.K = c - kSegLog;
-  p.total_buckets = (size_t)p.W * p.nb;
-  p.total_segs = (size_t)p.W * p.nseg;
-  p.partial_count = (size_t)p.W * (p.K + 1);
-  uint32_t t = 64;
-  while (t < 1024 && t < std::max(1u, p.nseg / 2)) t <<= 1;
-  p.tree_threads = t;
+  const Plan p = make_reduce_plan(c, num_windows);
   int rc;
   const size_t in_bytes = (size_t)buckets_size * num_windows * 96;
   if ((rc = ensure(ctx, ctx->scratch_a, in_bytes))) return rc;
@@ -780,10 +758,8 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   if ((rc = ensure(ctx, ctx->buckets, p.total_buckets * sizeof(Jacobian)))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, buckets_be32, in_bytes, hipMemcpyHostToDevice, st));
   const size_t words = (size_t)buckets_size * num_windows * 3;
-  hipLaunchKernelGGL(be32_to_le_kernel, dim3((unsigned)((words * 8 + 255) / 256)), dim3(256), 0, st,
-                     (const uint32_t*)ctx->scratch_a.p, words, (uint32_t*)ctx->scratch_b.p);
-  hipLaunchKernelGGL(pad_buckets_kernel, dim3((unsigned)((p.total_buckets + 255) / 256)), dim3(256), 0, st,
-                     (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.c, (Jacobian*)ctx->buckets.p);
+  launch_be32_to_le(st, (const uint32_t*)ctx->scratch_a.p, words, (uint32_t*)ctx->scratch_b.p);
+  launch_pad_buckets(st, (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.c, (Jacobian*)ctx->buckets.p);
   if ((rc = enqueue_reduce(ctx, p, (const Jacobian*)ctx->buckets.p))) return rc;
   std::vector<Jacobian> partial(p.partial_count);
   HIP_TRY(ctx, hipMemcpyAsync(partial.data(), ctx->partial.p, p.partial_count * sizeof(Jacobian),
@@ -833,9 +809,8 @@ int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t*
   if ((rc = ensure(ctx, ctx->scratch_c, lo.size() * 4))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, la.data(), la.size() * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, lb.data(), lb.size() * 4, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(test_op_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, op,
-                     (const u256*)ctx->scratch_a.p, (const u256*)ctx->scratch_b.p, (u256*)ctx->scratch_c.p,
-                     (uint32_t)count);
+  launch_test_op(st, op, (const u256*)ctx->scratch_a.p, (const u256*)ctx->scratch_b.p, (u256*)ctx->scratch_c.p,
+                 (uint32_t)count);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(lo.data(), ctx->scratch_c.p, lo.size() * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
