@@ -43,13 +43,13 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     m = importlib.import_module("metal-msm-gpu-acceleration_amd")
+    mg = importlib.import_module("metal-msm-gpu-acceleration_amd.multi_gpu")
     cfg = m.setup_metal_state(local_rank)          # fails loudly without a gfx950 device
     n = 1 << args.log_size
     inst = args.instances
-    seed0 = 0xB2540000 + rank * inst               # instance j of rank r: seed 0xB2540000 + r*inst + j
     d_pts, d_sc = [], []
-    for j in range(inst):
-        dp, ds = cfg.generate_instance(seed0 + j, n, True)
+    for g in mg.instance_ids(rank, world, inst):   # rank r owns global instances r*inst .. r*inst+inst-1
+        dp, ds = cfg.generate_instance(mg.instance_seed(g), n, True)
         d_pts.append(dp)
         d_sc.append(ds)
     ns = [n] * inst
@@ -59,11 +59,8 @@ def main():
     def step():
         nonlocal gathered
         outs = cfg.msm_batch_device(d_sc, d_pts, ns)
-        if dist is not None:
-            mine = torch.frombuffer(bytearray(b"".join(outs)), dtype=torch.uint8).to(dev)
-            allr = torch.empty(world * mine.numel(), dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(allr, mine)      # RCCL gather of per-instance results over xGMI
-            gathered = allr
+        if dist is not None:                             # RCCL gather of per-instance results over xGMI
+            gathered = mg.all_gather_results(outs, dist, dev)
         return outs
 
     def barrier():

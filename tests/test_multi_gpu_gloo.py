@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: two gloo ranks shard instances and all-gather the 96-byte results
+(the GPU compute is replaced by the CPU oracle here; the sharding/gather code is the product's)."""
+import importlib
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, per_rank, n, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mg = importlib.import_module("metal-msm-gpu-acceleration_amd.multi_gpu")
+    from oracle import c_oracle as co
+    local = []
+    for g in mg.instance_ids(rank, world, per_rank):
+        pts, sc = co.gen_instance(mg.instance_seed(g), n, True, threads=1)
+        local.append(co.msm_best(sc, pts, n, 1))
+    allr = mg.all_gather_results(local, dist)
+    q.put((rank, allr))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_gather():
+    world, per_rank, n = 2, 3, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    mg = importlib.import_module("metal-msm-gpu-acceleration_amd.multi_gpu")
+    from oracle import c_oracle as co
+    expect = []
+    for g in range(world * per_rank):
+        pts, sc = co.gen_instance(mg.instance_seed(g), n, True, threads=1)
+        expect.append(co.msm_best(sc, pts, n, 1))
+    assert got[0] == expect and got[1] == expect          # every rank sees all results, in global order
+    # each instance is owned by exactly one rank
+    owners = [mg.instance_ids(r, world, per_rank) for r in range(world)]
+    assert sorted(sum(owners, [])) == list(range(world * per_rank))
+
+
+def test_single_process_passthrough():
+    sys.path.insert(0, ROOT)
+    mg = importlib.import_module("metal-msm-gpu-acceleration_amd.multi_gpu")
+    res = [bytes([i]) * 96 for i in range(4)]
+    assert mg.all_gather_results(res, None) == res
+    with pytest.raises(ValueError):
+        mg.all_gather_results([b"short"], None)
+    with pytest.raises(ValueError):
+        mg.instance_ids(2, 2, 1)
