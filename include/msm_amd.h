@@ -169,9 +169,25 @@ enum {
   MSM_AMD_OP_EC_ADD = 10,   /* bn254_add: Jacobian + Jacobian; a, b, out are 24 limbs */
   MSM_AMD_OP_EC_MUL = 11,   /* bn254_scalar_mul: a = point (24 limbs), b = scalar (8 limbs, canonical) */
   MSM_AMD_OP_EC_MADD = 12,  /* Jacobian a + affine b (b given as 24 limbs with z = one or z = 0) */
-  MSM_AMD_OP_EC_DBL = 13    /* 2 * a */
+  MSM_AMD_OP_EC_DBL = 13,   /* 2 * a */
+  /* ops of the 29-bit-limb internal representation the hot kernels compute in (csrc/bn254_fq29.hip.h);
+   * operands and results cross the boundary in the same external form as above */
+  MSM_AMD_OP_FP29_MUL = 14,
+  MSM_AMD_OP_FP29_SQR = 15,
+  MSM_AMD_OP_FP29_SUB_K4E30 = 16,  /* a - b through the lifted constant 4p */
+  MSM_AMD_OP_FP29_SUB_K8E30 = 17,
+  MSM_AMD_OP_FP29_SUB_K8E31 = 18,  /* a - 3b (lazy three-term subtrahend) */
+  MSM_AMD_OP_FP29_SUB_K16E30 = 19,
+  MSM_AMD_OP_FP29_SUB_K16E31 = 20, /* a - 3b */
+  MSM_AMD_OP_FP29_ROUNDTRIP = 21,  /* external -> internal -> external */
+  MSM_AMD_OP_EC29_MADD = 22,       /* Jacobian a + affine b on internal limbs */
+  MSM_AMD_OP_EC29_ADD = 23,        /* Jacobian a + Jacobian b on internal limbs */
+  MSM_AMD_OP_EC29_MADD_CHAIN = 24, /* a + 64 b: 64 chained mixed additions kept in the lazy internal form */
+  MSM_AMD_OP_EC29_ADD_CHAIN = 25   /* a + 16 b: 16 chained full additions */
 };
 int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count);
+/* The same operation bodies executed on the host CPU (no GPU needed): host-logic tests. */
+int msm_amd_test_op_host(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count);
 
 /* ---- introspection --------------------------------------------------------------------------- */
 int msm_amd_last_timings(const msm_amd_ctx* ctx, msm_amd_timings* out);

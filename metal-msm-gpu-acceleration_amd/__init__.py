@@ -19,7 +19,13 @@ SCALAR_MONT_LE, SCALAR_CANON_LE, SCALAR_CANON_BE32 = 0, 1, 2
 POINT_H2C_AFFINE, POINT_ARK_PROJECTIVE, POINT_ARK_AFFINE, POINT_JAC_BE32 = 0, 1, 2, 3
 POINT_BYTES = {POINT_H2C_AFFINE: 64, POINT_ARK_PROJECTIVE: 96, POINT_ARK_AFFINE: 72, POINT_JAC_BE32: 96}
 (OP_UINT_ADD, OP_UINT_SUB, OP_UINT_PROD, OP_UINT_SHL, OP_UINT_SHR, OP_FP_ADD, OP_FP_SUB, OP_FP_MUL, OP_FP_NEG,
- OP_FP_POW, OP_EC_ADD, OP_EC_MUL, OP_EC_MADD, OP_EC_DBL) = range(14)
+ OP_FP_POW, OP_EC_ADD, OP_EC_MUL, OP_EC_MADD, OP_EC_DBL, OP_FP29_MUL, OP_FP29_SQR, OP_FP29_SUB_K4E30,
+ OP_FP29_SUB_K8E30, OP_FP29_SUB_K8E31, OP_FP29_SUB_K16E30, OP_FP29_SUB_K16E31, OP_FP29_ROUNDTRIP, OP_EC29_MADD,
+ OP_EC29_ADD, OP_EC29_MADD_CHAIN, OP_EC29_ADD_CHAIN) = range(26)
+
+
+def op_is_point(op):
+    return 10 <= op <= 13 or op >= 22
 
 # every symbol include/msm_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -29,7 +35,8 @@ EXPORTS = [
     "msm_amd_msm_batch_device", "msm_amd_device_alloc", "msm_amd_device_free", "msm_amd_copy_to_device",
     "msm_amd_copy_to_host", "msm_amd_stream", "msm_amd_synchronize", "msm_amd_generate_instance",
     "msm_amd_prepare_buckets_indices", "msm_amd_sort_buckets_indices", "msm_amd_bucket_wise_accumulation",
-    "msm_amd_sum_reduction", "msm_amd_final_accumulation", "msm_amd_test_op", "msm_amd_last_timings",
+    "msm_amd_sum_reduction", "msm_amd_final_accumulation", "msm_amd_test_op", "msm_amd_test_op_host",
+    "msm_amd_last_timings",
     "msm_amd_algorithmic_bytes", "msm_amd_version",
 ]
 
@@ -93,6 +100,7 @@ def _lib():
         L.msm_amd_sum_reduction.argtypes = [c_void_p, c_void_p, c_uint32, c_uint32, c_void_p]
         L.msm_amd_final_accumulation.argtypes = [c_void_p, c_uint32, c_uint32, c_void_p]
         L.msm_amd_test_op.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t]
+        L.msm_amd_test_op_host.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_size_t]
         L.msm_amd_last_timings.argtypes = [c_void_p, POINTER(Timings)]
         L.msm_amd_algorithmic_bytes.argtypes = [c_size_t, c_uint32, c_int]
         L.msm_amd_algorithmic_bytes.restype = c_uint64
@@ -231,10 +239,20 @@ class MsmConfig:
         return [list(out[24 * i:24 * i + 24]) for i in range(num_windows)]
 
     def test_op(self, op, a, b, count):
-        per = 24 if op >= OP_EC_ADD else 8
+        per = 24 if op_is_point(op) else 8
         out = (c_uint32 * (count * per))()
         self._check(_lib().msm_amd_test_op(self.h, op, _u32buf(a), _u32buf(b), out, count))
         return list(out)
+
+
+def test_op_host(op, a, b, count):
+    """Same single-op bodies as MsmConfig.test_op, executed on the host CPU by the library (no GPU)."""
+    per = 24 if op_is_point(op) else 8
+    out = (c_uint32 * (count * per))()
+    st = _lib().msm_amd_test_op_host(op, _u32buf(a), _u32buf(b), out, count)
+    if st != OK:
+        raise MsmError(st)
+    return list(out)
 
 
 def final_accumulation(res_be32, num_windows, window_size):

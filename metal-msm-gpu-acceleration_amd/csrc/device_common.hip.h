@@ -8,7 +8,8 @@
 //   chunk_prefix_kernel  counts -> bucket_size[W][nb], counts := exclusive prefix over chunks
 //   scan_kernel          bucket_size -> bucket_start[W][nb]  (per-window exclusive scan in LDS)
 //   scatter_kernel       digits + cursors -> sorted[W][n]  (point indices grouped by digit)
-//   accumulate_kernel    sorted + bases(affine 64 B) -> buckets[W][nb]  (Jacobian 96 B)   <- dominant
+//   convert_bases_kernel bases (affine 64 B, external limbs) -> bases29 (80 B, 29-bit internal limbs)
+//   accumulate_kernel    sorted + bases29 -> buckets[W][nb]  (Jacobian 112 B internal)        <- dominant
 //   reduce_seg_kernel    buckets -> S[W][nseg], T[W][nseg]   (segments of 8 buckets)
 //   reduce_tree_kernel   S, T -> partial[W][K+1]  (one plain sum + K bit-subset sums per window)
 //   host                 Horner over bit positions of the (K+1)*W partial points
@@ -25,7 +26,7 @@
 //     every combine, msm.h.metal:429-430).
 #pragma once
 #include <hip/hip_runtime.h>
-#include "bn254_ec.hip.h"
+#include "bn254_ec29.hip.h"
 #include "launch.h"
 
 namespace msm_amd {
@@ -105,6 +106,57 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
   return res;
 }
 
+#endif
+
+#if defined(__HIPCC__)
+// 16-byte vector loads/stores of the internal-representation points (80 B affine, 112 B Jacobian).
+template <int QUADS>
+__device__ __forceinline__ void load_quads(const void* p, uint32_t* dst) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < QUADS; ++i) {
+    const uint4 v = q[i];
+    dst[4 * i + 0] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+  }
+}
+template <int QUADS>
+__device__ __forceinline__ void store_quads(void* p, const uint32_t* src) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < QUADS; ++i) q[i] = make_uint4(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+}
+__device__ __forceinline__ AffI load_affi(const AffI* p) {
+  uint32_t w[20];
+  load_quads<5>(p, w);
+  AffI r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { r.x.l[i] = w[i]; r.y.l[i] = w[9 + i]; }
+  r.pad[0] = r.pad[1] = 0;
+  return r;
+}
+__device__ __forceinline__ void store_affi(AffI* p, const AffI& a) {
+  uint32_t w[20];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { w[i] = a.x.l[i]; w[9 + i] = a.y.l[i]; }
+  w[18] = w[19] = 0;
+  store_quads<5>(p, w);
+}
+__device__ __forceinline__ JacI load_jaci(const JacI* p) {
+  uint32_t w[28];
+  load_quads<7>(p, w);
+  JacI r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { r.x.l[i] = w[i]; r.y.l[i] = w[9 + i]; r.z.l[i] = w[18 + i]; }
+  r.pad = 0;
+  return r;
+}
+__device__ __forceinline__ void store_jaci(JacI* p, const JacI& a) {
+  uint32_t w[28];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { w[i] = a.x.l[i]; w[9 + i] = a.y.l[i]; w[18 + i] = a.z.l[i]; }
+  w[27] = 0;
+  store_quads<7>(p, w);
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 //   test_op_kernel          == the 12 single-thread test kernels of shader/tests/*.h.metal, batched
 #include "device_common.hip.h"
 #include "launch.h"
+#include "test_ops.hip.h"
 
 namespace msm_amd {
 
@@ -147,67 +148,25 @@ ref_accumulate_kernel(const uint2* __restrict__ pairs, size_t n_pairs, const Jac
 // weight d: X[w][d] = B[w][d-1] for 1 <= d <= bs, identity elsewhere.
 __global__ void __launch_bounds__(256)
 pad_buckets_kernel(const Jacobian* __restrict__ in, uint32_t bs, uint32_t W, uint32_t c,
-                   Jacobian* __restrict__ out) {
+                   JacI* __restrict__ out) {
   const uint32_t nb = 1u << c;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= W * nb) return;
   const uint32_t w = t >> c, d = t & (nb - 1);
   Jacobian v = jac_identity();
   if (d >= 1 && d <= bs) v = load_jac(&in[(size_t)w * bs + d - 1]);
-  store_jac(&out[t], v);
+  store_jaci(&out[t], jaci_from_ext(v));   // production window reduction works on internal limbs
 }
 
 // ------------------------------------------------------------------------------------------------
-// Batched single-op kernel.  a, b, out are little-endian device copies; stride in u256 units is 1 for
-// integer/field ops and 3 for points.
+// Batched single-op kernel (bodies in test_ops.hip.h).
 __global__ void __launch_bounds__(64)
 test_op_kernel(int op, const u256* __restrict__ a, const u256* __restrict__ b, u256* __restrict__ out,
                uint32_t count) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count) return;
-  if (op <= 9) {
-    const u256 x = load_u256(&a[t]);
-    const u256 y = load_u256(&b[t]);
-    u256 r = u256_zero();
-    switch (op) {
-      case 0: u256_add(r, x, y); break;
-      case 1: u256_sub(r, x, y); break;
-      case 2: r = u256_mul_u32(x, y.v[0]); break;
-      case 3: r = u256_shl(x, y.v[0] & 255u); break;
-      case 4: r = u256_shr(x, y.v[0] & 255u); break;
-      case 5: r = Fq::add(x, y); break;
-      case 6: r = Fq::sub(x, y); break;
-      case 7: r = Fq::mul(x, y); break;
-      case 8: r = Fq::neg(x); break;
-      case 9: r = Fq::pow_u32(x, y.v[0]); break;
-    }
-    store_u256(&out[t], r);
-    return;
-  }
-  const Jacobian p = load_jac(reinterpret_cast<const Jacobian*>(a) + t);
-  Jacobian r = jac_identity();
-  if (op == 10) {
-    const Jacobian q = load_jac(reinterpret_cast<const Jacobian*>(b) + t);
-    r = jac_add(p, q);
-  } else if (op == 11) {
-    const u256 k = load_u256(&b[t]);
-    r = jac_scalar_mul(p, k);
-  } else if (op == 12) {
-    const Jacobian q = load_jac(reinterpret_cast<const Jacobian*>(b) + t);
-    if (jac_is_identity(q)) {
-      r = p;
-    } else {
-      Affine qa;
-      qa.x = q.x;
-      qa.y = q.y;
-      r = jac_madd(p, qa);
-    }
-  } else if (op == 13) {
-    r = jac_double(p);
-  }
-  store_jac(reinterpret_cast<Jacobian*>(out) + t, r);
+  run_test_op(op, a, b, out, t);
 }
-
 
 // ------------------------------------------------------------------------------------------------
 void launch_ref_prepare(hipStream_t st, const u256* scalars, uint32_t n, uint32_t c, uint32_t W, uint2* pairs) {
@@ -239,7 +198,7 @@ void launch_ref_accumulate(hipStream_t st, const uint2* pairs, size_t n_pairs, c
                      points, n_points, total_buckets, buckets);
 }
 
-void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t c, Jacobian* out) {
+void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t c, JacI* out) {
   const size_t total = (size_t)W << c;
   hipLaunchKernelGGL(pad_buckets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, bs, W, c, out);
 }

@@ -19,6 +19,7 @@
 #include "../../include/msm_amd.h"
 #include "device_common.hip.h"
 #include "launch.h"
+#include "test_ops.hip.h"
 
 using namespace msm_amd;
 
@@ -50,7 +51,7 @@ struct msm_amd_ctx {
   std::string last_error;
   uint32_t forced_window = 0;
   DeviceBuf digits, counts, bsize, bstart, istart, win_items, size_bins, sorted, order, multi_list, counters,
-      buckets, item_partials, S, T, partial, conv_scalars, conv_points, scratch_a, scratch_b, scratch_c;
+      bases29, buckets, item_partials, S, T, partial, conv_scalars, conv_points, scratch_a, scratch_b, scratch_c;
   std::vector<InstanceSlot> slots;
   msm_amd_timings timings{};
 };
@@ -294,13 +295,13 @@ size_t point_bytes(int layout) {
 }
 
 // Window reduction of a production-layout bucket matrix: buckets [W][nb] -> partial [W][K+1] on device.
-int enqueue_reduce(msm_amd_ctx* ctx, const Plan& p, const Jacobian* buckets) {
+int enqueue_reduce(msm_amd_ctx* ctx, const Plan& p, const JacI* buckets) {
   hipStream_t st = ctx->stream;
   int rc;
-  if ((rc = ensure(ctx, ctx->S, p.total_segs * sizeof(Jacobian)))) return rc;
-  if ((rc = ensure(ctx, ctx->T, p.total_segs * sizeof(Jacobian)))) return rc;
+  if ((rc = ensure(ctx, ctx->S, p.total_segs * sizeof(JacI)))) return rc;
+  if ((rc = ensure(ctx, ctx->T, p.total_segs * sizeof(JacI)))) return rc;
   if ((rc = ensure(ctx, ctx->partial, p.partial_count * sizeof(Jacobian)))) return rc;
-  launch_reduce(st, p, buckets, (Jacobian*)ctx->S.p, (Jacobian*)ctx->T.p, (Jacobian*)ctx->partial.p);
+  launch_reduce(st, p, buckets, (JacI*)ctx->S.p, (JacI*)ctx->T.p, (Jacobian*)ctx->partial.p);
   HIP_TRY(ctx, hipGetLastError());
   return MSM_AMD_OK;
 }
@@ -325,8 +326,9 @@ int enqueue_msm(msm_amd_ctx* ctx, InstanceSlot& slot, int scalar_layout, int poi
   if ((rc = ensure(ctx, ctx->order, p.max_items * sizeof(uint2)))) return rc;
   if ((rc = ensure(ctx, ctx->multi_list, p.max_items * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, ctx->counters, sizeof(PlanCounters)))) return rc;
-  if ((rc = ensure(ctx, ctx->buckets, p.total_buckets * sizeof(Jacobian)))) return rc;
-  if ((rc = ensure(ctx, ctx->item_partials, p.max_items * sizeof(Jacobian)))) return rc;
+  if ((rc = ensure(ctx, ctx->bases29, n * sizeof(AffI)))) return rc;
+  if ((rc = ensure(ctx, ctx->buckets, p.total_buckets * sizeof(JacI)))) return rc;
+  if ((rc = ensure(ctx, ctx->item_partials, p.max_items * sizeof(JacI)))) return rc;
   SortBuffers sb{};
   sb.digits = (uint16_t*)ctx->digits.p;
   sb.counts = (uint32_t*)ctx->counts.p;
@@ -345,6 +347,7 @@ int enqueue_msm(msm_amd_ctx* ctx, InstanceSlot& slot, int scalar_layout, int poi
   const Affine* pts = nullptr;
   int sc_mont = 0;
   if ((rc = convert_inputs(ctx, scalar_layout, point_layout, d_scalars, d_points, n, &sc, &sc_mont, &pts))) return rc;
+  launch_convert_bases(st, pts, p.n, (AffI*)ctx->bases29.p);   // 8 x u32 limbs -> 9 x 29-bit internal limbs
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_CONVERT], st));
 
   launch_digits(st, p, sc, sc_mont, sb.digits);
@@ -353,10 +356,10 @@ int enqueue_msm(msm_amd_ctx* ctx, InstanceSlot& slot, int scalar_layout, int poi
   launch_sort(st, p, sb);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_SORT], st));
 
-  launch_accumulate(st, p, pts, sb, (Jacobian*)ctx->buckets.p, (Jacobian*)ctx->item_partials.p);
+  launch_accumulate(st, p, (const AffI*)ctx->bases29.p, sb, (JacI*)ctx->buckets.p, (JacI*)ctx->item_partials.p);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
 
-  if ((rc = enqueue_reduce(ctx, p, (const Jacobian*)ctx->buckets.p))) return rc;
+  if ((rc = enqueue_reduce(ctx, p, (const JacI*)ctx->buckets.p))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial, ctx->partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_REDUCE], st));
@@ -549,7 +552,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   DeviceBuf* bufs[] = {&ctx->digits, &ctx->counts, &ctx->bsize, &ctx->bstart, &ctx->istart, &ctx->win_items,
-                       &ctx->size_bins, &ctx->sorted, &ctx->order, &ctx->multi_list, &ctx->counters, &ctx->buckets,
+                       &ctx->size_bins, &ctx->sorted, &ctx->order, &ctx->multi_list, &ctx->counters, &ctx->bases29, &ctx->buckets,
                        &ctx->item_partials, &ctx->S, &ctx->T, &ctx->partial, &ctx->conv_scalars, &ctx->conv_points,
                        &ctx->scratch_a, &ctx->scratch_b, &ctx->scratch_c};
   for (DeviceBuf* b : bufs)
@@ -755,12 +758,12 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   const size_t in_bytes = (size_t)buckets_size * num_windows * 96;
   if ((rc = ensure(ctx, ctx->scratch_a, in_bytes))) return rc;
   if ((rc = ensure(ctx, ctx->scratch_b, in_bytes))) return rc;
-  if ((rc = ensure(ctx, ctx->buckets, p.total_buckets * sizeof(Jacobian)))) return rc;
+  if ((rc = ensure(ctx, ctx->buckets, p.total_buckets * sizeof(JacI)))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, buckets_be32, in_bytes, hipMemcpyHostToDevice, st));
   const size_t words = (size_t)buckets_size * num_windows * 3;
   launch_be32_to_le(st, (const uint32_t*)ctx->scratch_a.p, words, (uint32_t*)ctx->scratch_b.p);
-  launch_pad_buckets(st, (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.c, (Jacobian*)ctx->buckets.p);
-  if ((rc = enqueue_reduce(ctx, p, (const Jacobian*)ctx->buckets.p))) return rc;
+  launch_pad_buckets(st, (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.c, (JacI*)ctx->buckets.p);
+  if ((rc = enqueue_reduce(ctx, p, (const JacI*)ctx->buckets.p))) return rc;
   std::vector<Jacobian> partial(p.partial_count);
   HIP_TRY(ctx, hipMemcpyAsync(partial.data(), ctx->partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, st));
@@ -787,17 +790,22 @@ int msm_amd_final_accumulation(const uint32_t* res_be32, uint32_t num_windows, u
   return MSM_AMD_OK;
 }
 
+// Layout helper for the test-op entry points: limb reversal between the BE32 wire format and LE u256.
+static void test_op_widths(int op, size_t* wa, size_t* wb) {
+  const bool pt = test_op_is_point(op);
+  *wa = pt ? 3 : 1;
+  *wb = (op == MSM_AMD_OP_EC_MUL) ? 1 : *wa;
+}
+
 int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count) {
-  if (!ctx || !a || !b || !out || count == 0 || op < 0 || op > MSM_AMD_OP_EC_DBL)
+  if (!ctx || !a || !b || !out || count == 0 || op < 0 || op > kTestOpMax)
     return fail(ctx, MSM_AMD_INPUT_ERROR, "bad test_op arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  const bool pt = op >= MSM_AMD_OP_EC_ADD;
-  const size_t wa = pt ? 3 : 1;
-  const size_t wb = (op == MSM_AMD_OP_EC_MUL) ? 1 : wa;
+  size_t wa, wb;
+  test_op_widths(op, &wa, &wb);
   const size_t wo = wa;
-  // host-side limb reversal (tiny inputs), device buffers in LE
   std::vector<uint32_t> la(count * wa * 8), lb(count * wb * 8), lo(count * wo * 8);
   for (size_t i = 0; i < count * wa; ++i)
     for (int l = 0; l < 8; ++l) la[i * 8 + l] = a[i * 8 + 7 - l];
@@ -816,6 +824,20 @@ int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t*
   HIP_TRY(ctx, hipStreamSynchronize(st));
   for (size_t i = 0; i < count * wo; ++i)
     for (int l = 0; l < 8; ++l) out[i * 8 + l] = lo[i * 8 + 7 - l];
+  return MSM_AMD_OK;
+}
+
+int msm_amd_test_op_host(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count) {
+  if (!a || !b || !out || count == 0 || op < 0 || op > kTestOpMax) return MSM_AMD_INPUT_ERROR;
+  size_t wa, wb;
+  test_op_widths(op, &wa, &wb);
+  const size_t wo = wa;
+  // the op bodies index points as 3 consecutive u256 per element, scalars of EC_MUL as 1 per element
+  std::vector<u256> la(count * wa), lb(count * std::max(wb, wa)), lo(count * wo);
+  for (size_t i = 0; i < count * wa; ++i) la[i] = be32_to_u256(a + i * 8);
+  for (size_t i = 0; i < count * wb; ++i) lb[i] = be32_to_u256(b + i * 8);
+  for (size_t t = 0; t < count; ++t) run_test_op(op, la.data(), lb.data(), lo.data(), (uint32_t)t);
+  for (size_t i = 0; i < count * wo; ++i) u256_to_be32(lo[i], out + i * 8);
   return MSM_AMD_OK;
 }
 

@@ -1,0 +1,106 @@
+// Single-operation test bodies shared by the device test kernel (k_stage.hip) and the host-side test entry
+// point msm_amd_test_op_host: the same source runs on a GPU lane and on a CPU core.  Mirrors the reference's
+// one-thread test kernels (src/metal/shader/tests/*.h.metal, curves/bn254.h.metal) and adds the ops of the
+// 29-bit-limb internal representation used by the hot kernels.
+#pragma once
+#include "bn254_ec29.hip.h"
+
+namespace msm_amd {
+
+// a, b, out: little-endian u256 arrays; element t uses 1 (integer/field ops) or 3 (points) consecutive u256.
+MSM_HD void run_test_op(int op, const u256* a, const u256* b, u256* out, uint32_t t) {
+  if (op <= 9 || (op >= 14 && op <= 21)) {
+    const u256 x = a[t];
+    const u256 y = b[t];
+    u256 r = u256_zero();
+    switch (op) {
+      case 0: u256_add(r, x, y); break;
+      case 1: u256_sub(r, x, y); break;
+      case 2: r = u256_mul_u32(x, y.v[0]); break;
+      case 3: r = u256_shl(x, y.v[0] & 255u); break;
+      case 4: r = u256_shr(x, y.v[0] & 255u); break;
+      case 5: r = Fq::add(x, y); break;
+      case 6: r = Fq::sub(x, y); break;
+      case 7: r = Fq::mul(x, y); break;
+      case 8: r = Fq::neg(x); break;
+      case 9: r = Fq::pow_u32(x, y.v[0]); break;
+      default: {
+        const fe29 xi = Fq29::from_ext(x);
+        const fe29 yi = Fq29::from_ext(y);
+        const fe29 y3 = Fq29::add(yi, Fq29::add(yi, yi));
+        fe29 ri = Fq29::zero();
+        switch (op) {
+          case 14: ri = Fq29::mul(xi, yi); break;
+          case 15: ri = Fq29::sqr(xi); break;
+          case 16: ri = Fq29::norm(Fq29::sub<K4E30>(xi, yi)); break;
+          case 17: ri = Fq29::norm(Fq29::sub<K8E30>(xi, yi)); break;
+          case 18: ri = Fq29::norm(Fq29::sub<K8E31>(xi, y3)); break;
+          case 19: ri = Fq29::norm(Fq29::sub<K16E30>(xi, yi)); break;
+          case 20: ri = Fq29::norm(Fq29::sub<K16E31>(xi, y3)); break;
+          case 21: ri = xi; break;
+        }
+        r = Fq29::to_ext(ri);
+      }
+    }
+    out[t] = r;
+    return;
+  }
+  const Jacobian* pa = reinterpret_cast<const Jacobian*>(a);
+  const Jacobian* pb = reinterpret_cast<const Jacobian*>(b);
+  Jacobian* po = reinterpret_cast<Jacobian*>(out);
+  const Jacobian p = pa[t];
+  Jacobian r = jac_identity();
+  if (op == 10) {
+    r = jac_add(p, pb[t]);
+  } else if (op == 11) {
+    r = jac_scalar_mul(p, b[t]);
+  } else if (op == 12) {
+    const Jacobian q = pb[t];
+    if (jac_is_identity(q)) {
+      r = p;
+    } else {
+      Affine qa;
+      qa.x = q.x;
+      qa.y = q.y;
+      r = jac_madd(p, qa);
+    }
+  } else if (op == 13) {
+    r = jac_double(p);
+  } else if (op == 22) {   // internal representation: Jacobian + affine (b given with z = one or z = 0)
+    const Jacobian q = pb[t];
+    const JacI pi = jaci_from_ext(p);
+    if (jac_is_identity(q)) {
+      r = jaci_to_ext(pi);
+    } else {
+      Affine qa;
+      qa.x = q.x;
+      qa.y = q.y;
+      const AffI qi = affi_from_ext(qa);
+      r = jaci_to_ext(jaci_is_identity(pi) ? jaci_from_affi(qi) : jaci_madd(pi, qi));
+    }
+  } else if (op == 23) {   // internal representation: Jacobian + Jacobian
+    r = jaci_to_ext(jaci_add(jaci_from_ext(p), jaci_from_ext(pb[t])));
+  } else if (op == 24) {   // 64 chained mixed additions without leaving the lazy internal form: p + 64 q
+    const Jacobian q = pb[t];
+    JacI acc = jaci_from_ext(p);
+    if (!jac_is_identity(q)) {
+      Affine qa;
+      qa.x = q.x;
+      qa.y = q.y;
+      const AffI qi = affi_from_ext(qa);
+      for (int i = 0; i < 64; ++i) acc = jaci_is_identity(acc) ? jaci_from_affi(qi) : jaci_madd(acc, qi);
+    }
+    r = jaci_to_ext(acc);
+  } else if (op == 25) {   // 16 chained full additions: p + 16 q with q Jacobian
+    const JacI qi = jaci_from_ext(pb[t]);
+    JacI acc = jaci_from_ext(p);
+    for (int i = 0; i < 16; ++i) acc = jaci_add(acc, qi);
+    r = jaci_to_ext(acc);
+  }
+  po[t] = r;
+}
+
+constexpr int kTestOpMax = 25;
+MSM_HD bool test_op_is_point(int op) { return (op >= 10 && op <= 13) || op >= 22; }
+
+}  // namespace msm_amd
