@@ -249,8 +249,14 @@ MSM_HD bool gen_point_attempt(uint64_t seed, uint64_t i, uint32_t attempt, Affin
 }
 
 MSM_HD u256 gen_scalar_canonical(uint64_t seed, uint64_t i) {
-  u256 raw = rnd256(seed, 1, i);
-  raw.v[7] &= 0x3FFFFFFFu;
+  // rejection sampling: uniform mod r (254 random bits per attempt, accept if < r)
+  u256 raw = u256_zero();
+  for (uint32_t attempt = 0; attempt < 16; ++attempt) {
+    raw = rnd256(seed, 1, i * 16 + attempt);
+    raw.v[7] &= 0x3FFFFFFFu;
+    u256 d;
+    if (u256_sub(d, raw, Fr::modulus()) != 0) return raw;   // borrow: raw < r
+  }
   return Fr::reduce_once(raw);
 }
 

@@ -51,36 +51,62 @@ accumulate_kernel(const AffI* __restrict__ bases, const uint32_t* __restrict__ s
   }
 }
 
-// Buckets that were split into several items: one 64-lane workgroup per listed bucket (grid-stride over
-// multi_list), lanes sum the partials strided, then a 6-level LDS tree.  Only runs into work for skewed
-// digit distributions (equal scalars, the narrow top window of small window sizes).
+// Buckets that were split into several items (only skewed digit distributions produce them: equal scalars,
+// the narrow top window of small window sizes).  Each 64-lane workgroup takes 64 listed buckets at a time:
+// a lane sums its bucket's partials serially when there are at most kSerialItems of them; buckets with more
+// partials are then handled one by one by the whole workgroup (strided partial sums + 6-level LDS tree).
+constexpr uint32_t kSerialItems = 8;
+
 __global__ void __launch_bounds__(64)
 combine_kernel(const uint32_t* __restrict__ multi_list, const PlanCounters* __restrict__ counters,
                const uint32_t* __restrict__ bucket_size, const uint32_t* __restrict__ item_start,
                const uint32_t* __restrict__ win_base, uint32_t c, uint32_t CH,
                const JacI* __restrict__ partials, JacI* __restrict__ buckets) {
   __shared__ JacI sh[64];
+  __shared__ uint32_t big_b[64];
+  __shared__ uint32_t big_n;
   const uint32_t count = counters->multi_count;
-  for (uint32_t m = blockIdx.x; m < count; m += gridDim.x) {
-    const uint32_t b = multi_list[m];
-    const uint32_t w = b >> c;
-    const uint32_t nitems = (bucket_size[b] + CH - 1) / CH;
-    const JacI* src = partials + (size_t)win_base[w] + item_start[b];
-    JacI acc = jaci_identity();
-#pragma unroll 1
-    for (uint32_t i = threadIdx.x; i < nitems; i += 64) acc = jaci_add(acc, load_jaci(&src[i]));
-    store_jaci(&sh[threadIdx.x], acc);
+  for (uint32_t base = blockIdx.x * 64; base < count; base += gridDim.x * 64) {
+    if (threadIdx.x == 0) big_n = 0;
     __syncthreads();
+    const uint32_t m = base + threadIdx.x;
+    if (m < count) {
+      const uint32_t b = multi_list[m];
+      const uint32_t nitems = (bucket_size[b] + CH - 1) / CH;
+      if (nitems <= kSerialItems) {
+        const JacI* src = partials + (size_t)win_base[b >> c] + item_start[b];
+        JacI acc = load_jaci(&src[0]);
 #pragma unroll 1
-    for (uint32_t stride = 32; stride >= 1; stride >>= 1) {
-      if (threadIdx.x < stride) {
-        const JacI a = load_jaci(&sh[threadIdx.x]);
-        const JacI b2 = load_jaci(&sh[threadIdx.x + stride]);
-        store_jaci(&sh[threadIdx.x], jaci_add(a, b2));
+        for (uint32_t i = 1; i < nitems; ++i) acc = jaci_add(acc, load_jaci(&src[i]));
+        store_jaci(&buckets[b], acc);
+      } else {
+        big_b[atomicAdd(&big_n, 1u)] = b;
       }
+    }
+    __syncthreads();
+    const uint32_t nbig = big_n;
+#pragma unroll 1
+    for (uint32_t k = 0; k < nbig; ++k) {
+      const uint32_t b = big_b[k];
+      const uint32_t nitems = (bucket_size[b] + CH - 1) / CH;
+      const JacI* src = partials + (size_t)win_base[b >> c] + item_start[b];
+      JacI acc = jaci_identity();
+#pragma unroll 1
+      for (uint32_t i = threadIdx.x; i < nitems; i += 64) acc = jaci_add(acc, load_jaci(&src[i]));
+      store_jaci(&sh[threadIdx.x], acc);
+      __syncthreads();
+#pragma unroll 1
+      for (uint32_t stride = 32; stride >= 1; stride >>= 1) {
+        if (threadIdx.x < stride) {
+          const JacI x = load_jaci(&sh[threadIdx.x]);
+          const JacI y = load_jaci(&sh[threadIdx.x + stride]);
+          store_jaci(&sh[threadIdx.x], jaci_add(x, y));
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) store_jaci(&buckets[b], load_jaci(&sh[0]));
       __syncthreads();
     }
-    if (threadIdx.x == 0) store_jaci(&buckets[b], load_jaci(&sh[0]));
     __syncthreads();
   }
 }
@@ -93,7 +119,7 @@ void launch_accumulate(hipStream_t st, const Plan& p, const AffI* bases, const S
                      (const uint32_t*)b.sorted, (const uint32_t*)b.bucket_start, (const uint32_t*)b.bucket_size,
                      (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, (const uint2*)b.order,
                      (const PlanCounters*)b.counters, p.n, p.c, p.CH, buckets, partials);
-  hipLaunchKernelGGL(combine_kernel, dim3(1024), dim3(64), 0, st, (const uint32_t*)b.multi_list,
+  hipLaunchKernelGGL(combine_kernel, dim3(256), dim3(64), 0, st, (const uint32_t*)b.multi_list,
                      (const PlanCounters*)b.counters, (const uint32_t*)b.bucket_size, (const uint32_t*)b.item_start,
                      (const uint32_t*)b.win_items, p.c, p.CH, (const JacI*)partials, buckets);
 }

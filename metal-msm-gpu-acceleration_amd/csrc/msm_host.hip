@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -44,14 +45,26 @@ struct InstanceSlot {
 
 }  // namespace
 
+// Device buffers of one in-flight MSM.  A ctx owns kStreams of these, each with its own HIP stream:
+// instance i of a batch runs on workspace i % nstreams, so the latency-bound tail of one instance (window
+// reduction, planning kernels) overlaps the throughput-bound bucket accumulation of the next one.
+struct Workspace {
+  hipStream_t stream = nullptr;
+  DeviceBuf digits, counts, bsize, bstart, istart, win_items, size_bins, sorted, order, multi_list, counters,
+      bases29, buckets, item_partials, S, T, partial, conv_scalars, conv_points, conv_tmp;
+};
+
+constexpr int kMaxStreams = 4;
+
 struct msm_amd_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // == ws[0].stream; used by the stage / helper entry points
+  int nstreams = 1;
+  Workspace ws[kMaxStreams];
   std::mutex mu;
   std::string last_error;
   uint32_t forced_window = 0;
-  DeviceBuf digits, counts, bsize, bstart, istart, win_items, size_bins, sorted, order, multi_list, counters,
-      bases29, buckets, item_partials, S, T, partial, conv_scalars, conv_points, scratch_a, scratch_b, scratch_c;
+  DeviceBuf scratch_a, scratch_b, scratch_c;
   std::vector<InstanceSlot> slots;
   msm_amd_timings timings{};
 };
@@ -224,10 +237,10 @@ int slot_prepare(msm_amd_ctx* ctx, InstanceSlot& s, size_t partial_count) {
 
 // Bring inputs to the native device layout (affine 64 B Montgomery LE; scalars 32 B LE).
 // On return *scalars_native / *points_native point to device memory valid until the next call.
-int convert_inputs(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const void* d_scalars,
+int convert_inputs(msm_amd_ctx* ctx, Workspace& w, int scalar_layout, int point_layout, const void* d_scalars,
                    const void* d_points, size_t n, const u256** scalars_native, int* scalars_mont,
                    const Affine** points_native) {
-  hipStream_t st = ctx->stream;
+  hipStream_t st = w.stream;
   switch (scalar_layout) {
     case MSM_AMD_SCALAR_MONT_LE:
       *scalars_native = (const u256*)d_scalars;
@@ -238,10 +251,10 @@ int convert_inputs(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const 
       *scalars_mont = 0;
       break;
     case MSM_AMD_SCALAR_CANON_BE32: {
-      int rc = ensure(ctx, ctx->conv_scalars, n * 32);
+      int rc = ensure(ctx, w.conv_scalars, n * 32);
       if (rc) return rc;
-      launch_be32_to_le(st, (const uint32_t*)d_scalars, n, (uint32_t*)ctx->conv_scalars.p);
-      *scalars_native = (const u256*)ctx->conv_scalars.p;
+      launch_be32_to_le(st, (const uint32_t*)d_scalars, n, (uint32_t*)w.conv_scalars.p);
+      *scalars_native = (const u256*)w.conv_scalars.p;
       *scalars_mont = 0;
       break;
     }
@@ -253,27 +266,27 @@ int convert_inputs(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const 
       *points_native = (const Affine*)d_points;
       break;
     case MSM_AMD_POINT_ARK_PROJECTIVE: {
-      int rc = ensure(ctx, ctx->conv_points, n * sizeof(Affine));
+      int rc = ensure(ctx, w.conv_points, n * sizeof(Affine));
       if (rc) return rc;
-      launch_projective_to_affine(st, (const Jacobian*)d_points, (uint32_t)n, (Affine*)ctx->conv_points.p);
-      *points_native = (const Affine*)ctx->conv_points.p;
+      launch_projective_to_affine(st, (const Jacobian*)d_points, (uint32_t)n, (Affine*)w.conv_points.p);
+      *points_native = (const Affine*)w.conv_points.p;
       break;
     }
     case MSM_AMD_POINT_ARK_AFFINE: {
-      int rc = ensure(ctx, ctx->conv_points, n * sizeof(Affine));
+      int rc = ensure(ctx, w.conv_points, n * sizeof(Affine));
       if (rc) return rc;
-      launch_ark_affine_to_affine(st, (const uint8_t*)d_points, (uint32_t)n, (Affine*)ctx->conv_points.p);
-      *points_native = (const Affine*)ctx->conv_points.p;
+      launch_ark_affine_to_affine(st, (const uint8_t*)d_points, (uint32_t)n, (Affine*)w.conv_points.p);
+      *points_native = (const Affine*)w.conv_points.p;
       break;
     }
     case MSM_AMD_POINT_JAC_BE32: {
-      int rc = ensure(ctx, ctx->scratch_a, n * sizeof(Jacobian));
+      int rc = ensure(ctx, w.conv_tmp, n * sizeof(Jacobian));
       if (rc) return rc;
-      rc = ensure(ctx, ctx->conv_points, n * sizeof(Affine));
+      rc = ensure(ctx, w.conv_points, n * sizeof(Affine));
       if (rc) return rc;
-      launch_be32_to_le(st, (const uint32_t*)d_points, n * 3, (uint32_t*)ctx->scratch_a.p);
-      launch_projective_to_affine(st, (const Jacobian*)ctx->scratch_a.p, (uint32_t)n, (Affine*)ctx->conv_points.p);
-      *points_native = (const Affine*)ctx->conv_points.p;
+      launch_be32_to_le(st, (const uint32_t*)d_points, n * 3, (uint32_t*)w.conv_tmp.p);
+      launch_projective_to_affine(st, (const Jacobian*)w.conv_tmp.p, (uint32_t)n, (Affine*)w.conv_points.p);
+      *points_native = (const Affine*)w.conv_points.p;
       break;
     }
     default:
@@ -295,59 +308,59 @@ size_t point_bytes(int layout) {
 }
 
 // Window reduction of a production-layout bucket matrix: buckets [W][nb] -> partial [W][K+1] on device.
-int enqueue_reduce(msm_amd_ctx* ctx, const Plan& p, const JacI* buckets) {
-  hipStream_t st = ctx->stream;
+int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, const Plan& p, const JacI* buckets) {
+  hipStream_t st = w.stream;
   int rc;
-  if ((rc = ensure(ctx, ctx->S, p.total_segs * sizeof(JacI)))) return rc;
-  if ((rc = ensure(ctx, ctx->T, p.total_segs * sizeof(JacI)))) return rc;
-  if ((rc = ensure(ctx, ctx->partial, p.partial_count * sizeof(Jacobian)))) return rc;
-  launch_reduce(st, p, buckets, (JacI*)ctx->S.p, (JacI*)ctx->T.p, (Jacobian*)ctx->partial.p);
+  if ((rc = ensure(ctx, w.S, p.total_segs * sizeof(JacI)))) return rc;
+  if ((rc = ensure(ctx, w.T, p.total_segs * sizeof(JacI)))) return rc;
+  if ((rc = ensure(ctx, w.partial, p.partial_count * sizeof(Jacobian)))) return rc;
+  launch_reduce(st, p, buckets, (JacI*)w.S.p, (JacI*)w.T.p, (Jacobian*)w.partial.p);
   HIP_TRY(ctx, hipGetLastError());
   return MSM_AMD_OK;
 }
 
 // Enqueue one whole MSM on the ctx stream; results land in slot.h_partial after slot.ev[EV_REDUCE].
-int enqueue_msm(msm_amd_ctx* ctx, InstanceSlot& slot, int scalar_layout, int point_layout, const void* d_scalars,
+int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_layout, int point_layout, const void* d_scalars,
                 const void* d_points, size_t n, Plan* plan_out) {
-  hipStream_t st = ctx->stream;
+  hipStream_t st = w.stream;
   const uint32_t c = ctx->forced_window ? ctx->forced_window : auto_window(n);
   const Plan p = make_plan(n, c);
   *plan_out = p;
   int rc;
   if ((rc = slot_prepare(ctx, slot, p.partial_count))) return rc;
-  if ((rc = ensure(ctx, ctx->digits, (size_t)p.W * n * sizeof(uint16_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->counts, (size_t)p.W * p.Q * p.nb * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->bsize, p.total_buckets * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->bstart, p.total_buckets * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->istart, p.total_buckets * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->win_items, 1024 * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->size_bins, 1025 * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->sorted, (size_t)p.W * n * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->order, p.max_items * sizeof(uint2)))) return rc;
-  if ((rc = ensure(ctx, ctx->multi_list, p.max_items * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->counters, sizeof(PlanCounters)))) return rc;
-  if ((rc = ensure(ctx, ctx->bases29, n * sizeof(AffI)))) return rc;
-  if ((rc = ensure(ctx, ctx->buckets, p.total_buckets * sizeof(JacI)))) return rc;
-  if ((rc = ensure(ctx, ctx->item_partials, p.max_items * sizeof(JacI)))) return rc;
+  if ((rc = ensure(ctx, w.digits, (size_t)p.W * n * sizeof(uint16_t)))) return rc;
+  if ((rc = ensure(ctx, w.counts, (size_t)p.W * p.Q * p.nb * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.bsize, p.total_buckets * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.bstart, p.total_buckets * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.istart, p.total_buckets * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.win_items, 1024 * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.size_bins, 1025 * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.sorted, (size_t)p.W * n * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.order, p.max_items * sizeof(uint2)))) return rc;
+  if ((rc = ensure(ctx, w.multi_list, p.max_items * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.counters, sizeof(PlanCounters)))) return rc;
+  if ((rc = ensure(ctx, w.bases29, n * sizeof(AffI)))) return rc;
+  if ((rc = ensure(ctx, w.buckets, p.total_buckets * sizeof(JacI)))) return rc;
+  if ((rc = ensure(ctx, w.item_partials, p.max_items * sizeof(JacI)))) return rc;
   SortBuffers sb{};
-  sb.digits = (uint16_t*)ctx->digits.p;
-  sb.counts = (uint32_t*)ctx->counts.p;
-  sb.bucket_size = (uint32_t*)ctx->bsize.p;
-  sb.bucket_start = (uint32_t*)ctx->bstart.p;
-  sb.item_start = (uint32_t*)ctx->istart.p;
-  sb.win_items = (uint32_t*)ctx->win_items.p;
-  sb.size_bins = (uint32_t*)ctx->size_bins.p;
-  sb.sorted = (uint32_t*)ctx->sorted.p;
-  sb.order = (uint2*)ctx->order.p;
-  sb.multi_list = (uint32_t*)ctx->multi_list.p;
-  sb.counters = (PlanCounters*)ctx->counters.p;
+  sb.digits = (uint16_t*)w.digits.p;
+  sb.counts = (uint32_t*)w.counts.p;
+  sb.bucket_size = (uint32_t*)w.bsize.p;
+  sb.bucket_start = (uint32_t*)w.bstart.p;
+  sb.item_start = (uint32_t*)w.istart.p;
+  sb.win_items = (uint32_t*)w.win_items.p;
+  sb.size_bins = (uint32_t*)w.size_bins.p;
+  sb.sorted = (uint32_t*)w.sorted.p;
+  sb.order = (uint2*)w.order.p;
+  sb.multi_list = (uint32_t*)w.multi_list.p;
+  sb.counters = (PlanCounters*)w.counters.p;
 
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_START], st));
   const u256* sc = nullptr;
   const Affine* pts = nullptr;
   int sc_mont = 0;
-  if ((rc = convert_inputs(ctx, scalar_layout, point_layout, d_scalars, d_points, n, &sc, &sc_mont, &pts))) return rc;
-  launch_convert_bases(st, pts, p.n, (AffI*)ctx->bases29.p);   // 8 x u32 limbs -> 9 x 29-bit internal limbs
+  if ((rc = convert_inputs(ctx, w, scalar_layout, point_layout, d_scalars, d_points, n, &sc, &sc_mont, &pts))) return rc;
+  launch_convert_bases(st, pts, p.n, (AffI*)w.bases29.p);   // 8 x u32 limbs -> 9 x 29-bit internal limbs
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_CONVERT], st));
 
   launch_digits(st, p, sc, sc_mont, sb.digits);
@@ -356,11 +369,11 @@ int enqueue_msm(msm_amd_ctx* ctx, InstanceSlot& slot, int scalar_layout, int poi
   launch_sort(st, p, sb);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_SORT], st));
 
-  launch_accumulate(st, p, (const AffI*)ctx->bases29.p, sb, (JacI*)ctx->buckets.p, (JacI*)ctx->item_partials.p);
+  launch_accumulate(st, p, (const AffI*)w.bases29.p, sb, (JacI*)w.buckets.p, (JacI*)w.item_partials.p);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
 
-  if ((rc = enqueue_reduce(ctx, p, (const JacI*)ctx->buckets.p))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial, ctx->partial.p, p.partial_count * sizeof(Jacobian),
+  if ((rc = enqueue_reduce(ctx, w, p, (const JacI*)w.buckets.p))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial, w.partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_REDUCE], st));
   HIP_TRY(ctx, hipGetLastError());
@@ -405,12 +418,14 @@ int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->slots.size() < n_inst) ctx->slots.resize(n_inst);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // inputs staged on stream 0 (uploads, generator) are complete
   std::vector<Plan> plans(n_inst);
   ctx->timings = msm_amd_timings{};
   for (size_t i = 0; i < n_inst; ++i) {
-    int rc = enqueue_msm(ctx, ctx->slots[i], scalar_layout, point_layout, d_scalars[i], d_points[i], n[i], &plans[i]);
+    Workspace& w = ctx->ws[i % (size_t)ctx->nstreams];
+    int rc = enqueue_msm(ctx, w, ctx->slots[i], scalar_layout, point_layout, d_scalars[i], d_points[i], n[i], &plans[i]);
     if (rc) {
-      (void)hipStreamSynchronize(ctx->stream);
+      for (int k = 0; k < ctx->nstreams; ++k) (void)hipStreamSynchronize(ctx->ws[k].stream);
       return rc;
     }
   }
@@ -424,7 +439,7 @@ int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size
     std::memcpy((uint8_t*)out_host + i * 96, &res, 96);
     accumulate_timings(ctx, s, plans[i], final_ms, n_inst);
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < ctx->nstreams; ++k) HIP_TRY(ctx, hipStreamSynchronize(ctx->ws[k].stream));
   return MSM_AMD_OK;
 }
 
@@ -509,14 +524,22 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   }
   msm_amd_ctx* ctx = new msm_amd_ctx();
   ctx->device = device;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-    delete ctx;
-    return MSM_AMD_PIPELINE_ERROR;
+  if (const char* e = std::getenv("MSM_AMD_STREAMS")) {
+    const int k = std::atoi(e);
+    if (k >= 1 && k <= kMaxStreams) ctx->nstreams = k;
   }
+  for (int k = 0; k < ctx->nstreams; ++k) {
+    if (hipStreamCreateWithFlags(&ctx->ws[k].stream, hipStreamNonBlocking) != hipSuccess) {
+      for (int j = 0; j < k; ++j) (void)hipStreamDestroy(ctx->ws[j].stream);
+      delete ctx;
+      return MSM_AMD_PIPELINE_ERROR;
+    }
+  }
+  ctx->stream = ctx->ws[0].stream;
   int rc = set_kernel_attributes(ctx);
   if (rc) {
     std::fprintf(stderr, "msm_amd: %s\n", ctx->last_error.c_str());
-    (void)hipStreamDestroy(ctx->stream);
+    for (int k = 0; k < ctx->nstreams; ++k) (void)hipStreamDestroy(ctx->ws[k].stream);
     delete ctx;
     return rc;
   }
@@ -550,19 +573,24 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (ctx == g_global_ctx) g_global_ctx = nullptr;
   }
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  DeviceBuf* bufs[] = {&ctx->digits, &ctx->counts, &ctx->bsize, &ctx->bstart, &ctx->istart, &ctx->win_items,
-                       &ctx->size_bins, &ctx->sorted, &ctx->order, &ctx->multi_list, &ctx->counters, &ctx->bases29, &ctx->buckets,
-                       &ctx->item_partials, &ctx->S, &ctx->T, &ctx->partial, &ctx->conv_scalars, &ctx->conv_points,
-                       &ctx->scratch_a, &ctx->scratch_b, &ctx->scratch_c};
-  for (DeviceBuf* b : bufs)
+  for (int k = 0; k < ctx->nstreams; ++k) (void)hipStreamSynchronize(ctx->ws[k].stream);
+  for (int k = 0; k < kMaxStreams; ++k) {
+    Workspace& w = ctx->ws[k];
+    DeviceBuf* bufs[] = {&w.digits, &w.counts, &w.bsize, &w.bstart, &w.istart, &w.win_items, &w.size_bins, &w.sorted,
+                         &w.order, &w.multi_list, &w.counters, &w.bases29, &w.buckets, &w.item_partials, &w.S, &w.T,
+                         &w.partial, &w.conv_scalars, &w.conv_points, &w.conv_tmp};
+    for (DeviceBuf* b : bufs)
+      if (b->p) (void)hipFree(b->p);
+  }
+  DeviceBuf* sbufs[] = {&ctx->scratch_a, &ctx->scratch_b, &ctx->scratch_c};
+  for (DeviceBuf* b : sbufs)
     if (b->p) (void)hipFree(b->p);
   for (InstanceSlot& s : ctx->slots) {
     if (s.has_events)
       for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(s.ev[i]);
     if (s.h_partial) (void)hipHostFree(s.h_partial);
   }
-  (void)hipStreamDestroy(ctx->stream);
+  for (int k = 0; k < ctx->nstreams; ++k) (void)hipStreamDestroy(ctx->ws[k].stream);
   delete ctx;
 }
 
@@ -651,7 +679,7 @@ int msm_amd_synchronize(msm_amd_ctx* ctx) {
   if (!ctx) return MSM_AMD_INPUT_ERROR;
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < ctx->nstreams; ++k) HIP_TRY(ctx, hipStreamSynchronize(ctx->ws[k].stream));
   return MSM_AMD_OK;
 }
 
@@ -725,17 +753,17 @@ int msm_amd_bucket_wise_accumulation(msm_amd_ctx* ctx, const uint32_t* sorted_pa
   if ((rc = ensure(ctx, ctx->scratch_a, std::max(pts_bytes, bkt_bytes)))) return rc;   // BE32 staging
   if ((rc = ensure(ctx, ctx->scratch_b, pts_bytes))) return rc;                        // points LE
   if ((rc = ensure(ctx, ctx->scratch_c, std::max<size_t>(n_pairs * 8, 8)))) return rc;
-  if ((rc = ensure(ctx, ctx->buckets, bkt_bytes))) return rc;
+  if ((rc = ensure(ctx, ctx->ws[0].buckets, bkt_bytes))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, points_be32, pts_bytes, hipMemcpyHostToDevice, st));
   launch_be32_to_le(st, (const uint32_t*)ctx->scratch_a.p, n_points * 3, (uint32_t*)ctx->scratch_b.p);
-  HIP_TRY(ctx, hipMemsetAsync(ctx->buckets.p, 0, bkt_bytes, st));   // Appendix B item 8: explicit zero fill
+  HIP_TRY(ctx, hipMemsetAsync(ctx->ws[0].buckets.p, 0, bkt_bytes, st));   // Appendix B item 8: explicit zero fill
   if (n_pairs) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, sorted_pairs, n_pairs * 8, hipMemcpyHostToDevice, st));
     launch_ref_accumulate(st, (const uint2*)ctx->scratch_c.p, n_pairs, (const Jacobian*)ctx->scratch_b.p,
-                          (uint32_t)n_points, total_buckets, (Jacobian*)ctx->buckets.p);
+                          (uint32_t)n_points, total_buckets, (Jacobian*)ctx->ws[0].buckets.p);
   }
   // LE -> BE32 is the same limb reversal
-  launch_be32_to_le(st, (const uint32_t*)ctx->buckets.p, (size_t)total_buckets * 3, (uint32_t*)ctx->scratch_a.p);
+  launch_be32_to_le(st, (const uint32_t*)ctx->ws[0].buckets.p, (size_t)total_buckets * 3, (uint32_t*)ctx->scratch_a.p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(buckets_out, ctx->scratch_a.p, bkt_bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -758,14 +786,14 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   const size_t in_bytes = (size_t)buckets_size * num_windows * 96;
   if ((rc = ensure(ctx, ctx->scratch_a, in_bytes))) return rc;
   if ((rc = ensure(ctx, ctx->scratch_b, in_bytes))) return rc;
-  if ((rc = ensure(ctx, ctx->buckets, p.total_buckets * sizeof(JacI)))) return rc;
+  if ((rc = ensure(ctx, ctx->ws[0].buckets, p.total_buckets * sizeof(JacI)))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, buckets_be32, in_bytes, hipMemcpyHostToDevice, st));
   const size_t words = (size_t)buckets_size * num_windows * 3;
   launch_be32_to_le(st, (const uint32_t*)ctx->scratch_a.p, words, (uint32_t*)ctx->scratch_b.p);
-  launch_pad_buckets(st, (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.c, (JacI*)ctx->buckets.p);
-  if ((rc = enqueue_reduce(ctx, p, (const JacI*)ctx->buckets.p))) return rc;
+  launch_pad_buckets(st, (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.c, (JacI*)ctx->ws[0].buckets.p);
+  if ((rc = enqueue_reduce(ctx, ctx->ws[0], p, (const JacI*)ctx->ws[0].buckets.p))) return rc;
   std::vector<Jacobian> partial(p.partial_count);
-  HIP_TRY(ctx, hipMemcpyAsync(partial.data(), ctx->partial.p, p.partial_count * sizeof(Jacobian),
+  HIP_TRY(ctx, hipMemcpyAsync(partial.data(), ctx->ws[0].partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   // per-window value: reuse the fused Horner with a single window

@@ -368,9 +368,14 @@ def _rnd256(seed, stream, ctr4):
 
 
 def gen_scalar(seed: int, i: int) -> int:
-    """Uniform-ish scalar mod r: 254 random bits, one conditional subtraction."""
-    v = _rnd256(seed, STREAM_SCALARS, i) & ((1 << 254) - 1)
-    return v - R_ORDER if v >= R_ORDER else v
+    """Uniform scalar mod r by rejection: 254 random bits per attempt (accept if < r, p = 0.756), up to 16
+    attempts; the 2^-32-probability fallback subtracts r once."""
+    v = 0
+    for attempt in range(16):
+        v = _rnd256(seed, STREAM_SCALARS, i * 16 + attempt) & ((1 << 254) - 1)
+        if v < R_ORDER:
+            return v
+    return v - R_ORDER
 
 
 def gen_point(seed: int, i: int):

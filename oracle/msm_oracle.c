@@ -215,9 +215,14 @@ static void gen_point(uint64_t seed, uint64_t i, aff_t* out) {
   memset(out, 0, sizeof(*out));
 }
 static void gen_scalar(uint64_t seed, uint64_t i, int mont, fe* out) {
-  fe raw; for (int k = 0; k < 4; ++k) raw.v[k] = rnd64(seed, 1, i * 4 + k);
-  raw.v[3] &= 0x3FFFFFFFFFFFFFFFull;
-  if (fe_geq(&raw, &FR.mod)) raw_sub(&raw, &raw, &FR.mod);
+  fe raw;
+  int ok = 0;
+  for (uint64_t attempt = 0; attempt < 16 && !ok; ++attempt) {   /* rejection sampling: uniform mod r */
+    for (int k = 0; k < 4; ++k) raw.v[k] = rnd64(seed, 1, (i * 16 + attempt) * 4 + k);
+    raw.v[3] &= 0x3FFFFFFFFFFFFFFFull;
+    ok = !fe_geq(&raw, &FR.mod);
+  }
+  if (!ok) raw_sub(&raw, &raw, &FR.mod);
   if (mont) f_to_mont(&FR, out, &raw); else *out = raw;
 }
 
