@@ -9,7 +9,7 @@
 //   scan_kernel          bucket_size -> bucket_start[W][nb]  (per-window exclusive scan in LDS)
 //   scatter_kernel       digits + cursors -> sorted[W][n]  (point indices grouped by digit)
 //   convert_bases_kernel bases (affine 64 B, external limbs) -> bases29 (80 B, 29-bit internal limbs)
-//   accumulate_kernel    sorted + bases29 -> buckets[W][nb]  (Jacobian 112 B internal)        <- dominant
+//   accumulate_kernel    sorted + bases29 -> buckets[W][nb]  (XYZZ 144 B internal)         <- dominant
 //   reduce_seg_kernel    buckets -> S[W][nseg], T[W][nseg]   (segments of 8 buckets)
 //   reduce_tree_kernel   S, T -> partial[W][K+1]  (one plain sum + K bit-subset sums per window)
 //   host                 Horner over bit positions of the (K+1)*W partial points
@@ -109,7 +109,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 #endif
 
 #if defined(__HIPCC__)
-// 16-byte vector loads/stores of the internal-representation points (80 B affine, 112 B Jacobian).
+// 16-byte vector loads/stores of the internal-representation points (80 B affine, 144 B XYZZ).
 template <int QUADS>
 __device__ __forceinline__ void load_quads(const void* p, uint32_t* dst) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
@@ -141,21 +141,19 @@ __device__ __forceinline__ void store_affi(AffI* p, const AffI& a) {
   w[18] = w[19] = 0;
   store_quads<5>(p, w);
 }
-__device__ __forceinline__ JacI load_jaci(const JacI* p) {
-  uint32_t w[28];
-  load_quads<7>(p, w);
-  JacI r;
+__device__ __forceinline__ PtI load_pti(const PtI* p) {
+  uint32_t w[36];
+  load_quads<9>(p, w);
+  PtI r;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { r.x.l[i] = w[i]; r.y.l[i] = w[9 + i]; r.z.l[i] = w[18 + i]; }
-  r.pad = 0;
+  for (int i = 0; i < 9; ++i) { r.x.l[i] = w[i]; r.y.l[i] = w[9 + i]; r.zz.l[i] = w[18 + i]; r.zzz.l[i] = w[27 + i]; }
   return r;
 }
-__device__ __forceinline__ void store_jaci(JacI* p, const JacI& a) {
-  uint32_t w[28];
+__device__ __forceinline__ void store_pti(PtI* p, const PtI& a) {
+  uint32_t w[36];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { w[i] = a.x.l[i]; w[9 + i] = a.y.l[i]; w[18 + i] = a.z.l[i]; }
-  w[27] = 0;
-  store_quads<7>(p, w);
+  for (int i = 0; i < 9; ++i) { w[i] = a.x.l[i]; w[9 + i] = a.y.l[i]; w[18 + i] = a.zz.l[i]; w[27 + i] = a.zzz.l[i]; }
+  store_quads<9>(p, w);
 }
 #endif
 

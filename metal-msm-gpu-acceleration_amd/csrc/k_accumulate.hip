@@ -7,7 +7,7 @@ namespace msm_amd {
 
 // One lane per work item.  A work item is (bucket b, chunk j): points [j*CH, min(size, (j+1)*CH)) of the
 // bucket's slice of `sorted`.  The lane gathers each 80-byte internal-form affine base (software-prefetched
-// one point ahead) and performs a mixed Jacobian+affine addition on 29-bit limbs (jaci_madd, 8M+3S).  Items arrive sorted by
+// one point ahead) and performs a mixed XYZZ+affine addition on 29-bit limbs (pti_madd, madd-2008-s, 8M+2S).  Items arrive sorted by
 // descending length (`order`), so the 64 lanes of a wave run the same number of iterations and the
 // longest items start first.  Replaces kernel bucket_wise_accumulation (msm.h.metal:75-315), which
 // splits pairs evenly over threads and merges bucket boundaries through threadgroup memory.
@@ -19,7 +19,7 @@ accumulate_kernel(const AffI* __restrict__ bases, const uint32_t* __restrict__ s
                   const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
                   const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
                   const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
-                  uint32_t c, uint32_t CH, JacI* __restrict__ buckets, JacI* __restrict__ partials) {
+                  uint32_t c, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= counters->total_items) return;
   const uint2 it = order[slot];
@@ -29,99 +29,104 @@ accumulate_kernel(const AffI* __restrict__ bases, const uint32_t* __restrict__ s
   const uint32_t lo = j * CH;
   const uint32_t cnt = min(size - lo, CH);
   const uint32_t* idx = sorted + (size_t)w * n + bucket_start[b] + lo;
-  JacI acc = jaci_identity();
+  PtI acc = pti_identity();
   uint32_t next_idx = idx[0];
 #pragma unroll 1
   for (uint32_t i = 0; i < cnt; ++i) {
-    // the gather of this point is issued here and first consumed after the Z1^2 squaring inside jaci_madd,
+    // the gather of this point is issued here and first consumed after the Z1^2 squaring inside pti_madd,
     // which hides most of its latency; only the next index is prefetched (one register, not a whole point)
     const AffI cur = load_affi(&bases[next_idx]);
     if (i + 1 < cnt) next_idx = idx[i + 1];
-    if (jaci_is_identity(acc)) {
-      if (!affi_is_identity(cur)) acc = jaci_from_affi(cur);
+    if (pti_is_identity(acc)) {
+      if (!affi_is_identity(cur)) acc = pti_from_affi(cur);
     } else {
-      const JacI sum = jaci_madd(acc, cur);
+      const PtI sum = pti_madd(acc, cur);
       if (!affi_is_identity(cur)) acc = sum;
     }
   }
   if (size <= CH) {
-    store_jaci(&buckets[b], acc);
+    store_pti(&buckets[b], acc);
   } else {
-    store_jaci(&partials[(size_t)win_base[w] + item_start[b] + j], acc);
+    store_pti(&partials[(size_t)win_base[w] + item_start[b] + j], acc);
   }
 }
 
 // Buckets that were split into several items (only skewed digit distributions produce them: equal scalars,
-// the narrow top window of small window sizes).  Each 64-lane workgroup takes 64 listed buckets at a time:
-// a lane sums its bucket's partials serially when there are at most kSerialItems of them; buckets with more
-// partials are then handled one by one by the whole workgroup (strided partial sums + 6-level LDS tree).
+// the narrow top window of small window sizes).  Two passes over multi_list:
+//   combine_small_kernel  one lane per listed bucket; sums up to kSerialItems partials serially, defers
+//                         larger buckets to big_list
+//   combine_big_kernel    one 64-lane workgroup per deferred bucket (grid-stride): strided partial sums +
+//                         6-level LDS tree
 constexpr uint32_t kSerialItems = 8;
 
 __global__ void __launch_bounds__(64)
-combine_kernel(const uint32_t* __restrict__ multi_list, const PlanCounters* __restrict__ counters,
-               const uint32_t* __restrict__ bucket_size, const uint32_t* __restrict__ item_start,
-               const uint32_t* __restrict__ win_base, uint32_t c, uint32_t CH,
-               const JacI* __restrict__ partials, JacI* __restrict__ buckets) {
-  __shared__ JacI sh[64];
-  __shared__ uint32_t big_b[64];
-  __shared__ uint32_t big_n;
+combine_small_kernel(const uint32_t* __restrict__ multi_list, PlanCounters* __restrict__ counters,
+                     const uint32_t* __restrict__ bucket_size, const uint32_t* __restrict__ item_start,
+                     const uint32_t* __restrict__ win_base, uint32_t c, uint32_t CH,
+                     const PtI* __restrict__ partials, PtI* __restrict__ buckets, uint32_t* __restrict__ big_list) {
   const uint32_t count = counters->multi_count;
-  for (uint32_t base = blockIdx.x * 64; base < count; base += gridDim.x * 64) {
-    if (threadIdx.x == 0) big_n = 0;
-    __syncthreads();
-    const uint32_t m = base + threadIdx.x;
-    if (m < count) {
-      const uint32_t b = multi_list[m];
-      const uint32_t nitems = (bucket_size[b] + CH - 1) / CH;
-      if (nitems <= kSerialItems) {
-        const JacI* src = partials + (size_t)win_base[b >> c] + item_start[b];
-        JacI acc = load_jaci(&src[0]);
+  for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < count; m += gridDim.x * blockDim.x) {
+    const uint32_t b = multi_list[m];
+    const uint32_t nitems = (bucket_size[b] + CH - 1) / CH;
+    if (nitems <= kSerialItems) {
+      const PtI* src = partials + (size_t)win_base[b >> c] + item_start[b];
+      PtI acc = load_pti(&src[0]);
 #pragma unroll 1
-        for (uint32_t i = 1; i < nitems; ++i) acc = jaci_add(acc, load_jaci(&src[i]));
-        store_jaci(&buckets[b], acc);
-      } else {
-        big_b[atomicAdd(&big_n, 1u)] = b;
-      }
+      for (uint32_t i = 1; i < nitems; ++i) acc = pti_add(acc, load_pti(&src[i]));
+      store_pti(&buckets[b], acc);
+    } else {
+      big_list[atomicAdd(&counters->pad[0], 1u)] = b;   // pad[0] = number of deferred buckets
     }
+  }
+}
+
+__global__ void __launch_bounds__(64)
+combine_big_kernel(const uint32_t* __restrict__ big_list, const PlanCounters* __restrict__ counters,
+                   const uint32_t* __restrict__ bucket_size, const uint32_t* __restrict__ item_start,
+                   const uint32_t* __restrict__ win_base, uint32_t c, uint32_t CH,
+                   const PtI* __restrict__ partials, PtI* __restrict__ buckets) {
+  __shared__ PtI sh[64];
+  const uint32_t count = counters->pad[0];
+  for (uint32_t m = blockIdx.x; m < count; m += gridDim.x) {
+    const uint32_t b = big_list[m];
+    const uint32_t nitems = (bucket_size[b] + CH - 1) / CH;
+    const PtI* src = partials + (size_t)win_base[b >> c] + item_start[b];
+    PtI acc = pti_identity();
+#pragma unroll 1
+    for (uint32_t i = threadIdx.x; i < nitems; i += 64) acc = pti_add(acc, load_pti(&src[i]));
+    store_pti(&sh[threadIdx.x], acc);
     __syncthreads();
-    const uint32_t nbig = big_n;
 #pragma unroll 1
-    for (uint32_t k = 0; k < nbig; ++k) {
-      const uint32_t b = big_b[k];
-      const uint32_t nitems = (bucket_size[b] + CH - 1) / CH;
-      const JacI* src = partials + (size_t)win_base[b >> c] + item_start[b];
-      JacI acc = jaci_identity();
-#pragma unroll 1
-      for (uint32_t i = threadIdx.x; i < nitems; i += 64) acc = jaci_add(acc, load_jaci(&src[i]));
-      store_jaci(&sh[threadIdx.x], acc);
-      __syncthreads();
-#pragma unroll 1
-      for (uint32_t stride = 32; stride >= 1; stride >>= 1) {
-        if (threadIdx.x < stride) {
-          const JacI x = load_jaci(&sh[threadIdx.x]);
-          const JacI y = load_jaci(&sh[threadIdx.x + stride]);
-          store_jaci(&sh[threadIdx.x], jaci_add(x, y));
-        }
-        __syncthreads();
+    for (uint32_t stride = 32; stride >= 1; stride >>= 1) {
+      if (threadIdx.x < stride) {
+        const PtI x = load_pti(&sh[threadIdx.x]);
+        const PtI y = load_pti(&sh[threadIdx.x + stride]);
+        store_pti(&sh[threadIdx.x], pti_add(x, y));
       }
-      if (threadIdx.x == 0) store_jaci(&buckets[b], load_jaci(&sh[0]));
       __syncthreads();
     }
+    if (threadIdx.x == 0) store_pti(&buckets[b], load_pti(&sh[0]));
     __syncthreads();
   }
 }
 
-void launch_accumulate(hipStream_t st, const Plan& p, const AffI* bases, const SortBuffers& b, JacI* buckets,
-                       JacI* partials) {
+void launch_accumulate(hipStream_t st, const Plan& p, const AffI* bases, const SortBuffers& b, PtI* buckets,
+                       PtI* partials) {
   // empty buckets produce no work item: all-zero memory is the identity (Z = 0)
-  (void)hipMemsetAsync(buckets, 0, p.total_buckets * sizeof(JacI), st);
+  (void)hipMemsetAsync(buckets, 0, p.total_buckets * sizeof(PtI), st);
   hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((p.max_items + 63) / 64)), dim3(64), 0, st, bases,
                      (const uint32_t*)b.sorted, (const uint32_t*)b.bucket_start, (const uint32_t*)b.bucket_size,
                      (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, (const uint2*)b.order,
                      (const PlanCounters*)b.counters, p.n, p.c, p.CH, buckets, partials);
-  hipLaunchKernelGGL(combine_kernel, dim3(256), dim3(64), 0, st, (const uint32_t*)b.multi_list,
+  // multi_list doubles as big_list storage: its second half (entries max_items/2 ..) is free because a split
+  // bucket accounts for at least two items
+  uint32_t* big_list = b.multi_list + p.max_items / 2 + 1;
+  hipLaunchKernelGGL(combine_small_kernel, dim3(256), dim3(64), 0, st, (const uint32_t*)b.multi_list, b.counters,
+                     (const uint32_t*)b.bucket_size, (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, p.c,
+                     p.CH, (const PtI*)partials, buckets, big_list);
+  hipLaunchKernelGGL(combine_big_kernel, dim3(512), dim3(64), 0, st, (const uint32_t*)big_list,
                      (const PlanCounters*)b.counters, (const uint32_t*)b.bucket_size, (const uint32_t*)b.item_start,
-                     (const uint32_t*)b.win_items, p.c, p.CH, (const JacI*)partials, buckets);
+                     (const uint32_t*)b.win_items, p.c, p.CH, (const PtI*)partials, buckets);
 }
 
 }  // namespace msm_amd

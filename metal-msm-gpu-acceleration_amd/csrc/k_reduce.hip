@@ -10,63 +10,63 @@ namespace msm_amd {
 // so that  sum_d d*X[d] = sum_s T[s] + 8 * sum_s s*S[s].   Replaces sum_reduction_partial
 // (msm.h.metal:319-461), whose combine step needs a scalar multiplication per merge.
 __global__ void __launch_bounds__(64)
-reduce_seg_kernel(const JacI* __restrict__ buckets, uint32_t total_segs,
-                  JacI* __restrict__ S, JacI* __restrict__ T) {
+reduce_seg_kernel(const PtI* __restrict__ buckets, uint32_t total_segs,
+                  PtI* __restrict__ S, PtI* __restrict__ T) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= total_segs) return;
-  const JacI* X = buckets + (size_t)s * kSeg;
-  JacI sum = jaci_identity(), sos = jaci_identity();
+  const PtI* X = buckets + (size_t)s * kSeg;
+  PtI sum = pti_identity(), sos = pti_identity();
 #pragma unroll 1
   for (int j = kSeg - 1; j >= 1; --j) {
-    sum = jaci_add(sum, load_jaci(&X[j]));
-    sos = jaci_add(sos, sum);
+    sum = pti_add(sum, load_pti(&X[j]));
+    sos = pti_add(sos, sum);
   }
-  sum = jaci_add(sum, load_jaci(&X[0]));
-  store_jaci(&S[s], sum);
-  store_jaci(&T[s], sos);
+  sum = pti_add(sum, load_pti(&X[0]));
+  store_pti(&S[s], sum);
+  store_pti(&T[s], sos);
 }
 
 // Stage 4b: tree sums.  grid = (K + 1, W) with K = c - 3 bits of segment index; block = tree_threads
-// (power of two, 64..1024); dynamic LDS = tree_threads * 112 bytes.
+// (power of two, 64..1024); dynamic LDS = tree_threads * 144 bytes.
 //   blockIdx.x == K : partial[w][K] = sum_s T[w][s]
 //   blockIdx.x  < K : partial[w][k] = sum over segments s with bit k set of S[w][s]
 // The host then evaluates  W_w = partial[w][K] + 8 * sum_k 2^k partial[w][k]  inside one Horner pass
 // over all bit positions (replaces sum_reduction_final msm.h.metal:463-562 and the doublings of
 // final_accumulation.rs:19-39).
 __global__ void __launch_bounds__(1024)
-reduce_tree_kernel(const JacI* __restrict__ S, const JacI* __restrict__ T, uint32_t nseg,
+reduce_tree_kernel(const PtI* __restrict__ S, const PtI* __restrict__ T, uint32_t nseg,
                    uint32_t K, Jacobian* __restrict__ partial) {
   extern __shared__ uint32_t lds_u32[];
-  JacI* sh = reinterpret_cast<JacI*>(lds_u32);
+  PtI* sh = reinterpret_cast<PtI*>(lds_u32);
   const uint32_t k = blockIdx.x, w = blockIdx.y;
-  const JacI* Sw = S + (size_t)w * nseg;
-  const JacI* Tw = T + (size_t)w * nseg;
-  JacI acc = jaci_identity();
+  const PtI* Sw = S + (size_t)w * nseg;
+  const PtI* Tw = T + (size_t)w * nseg;
+  PtI acc = pti_identity();
   if (k == K) {
 #pragma unroll 1
-    for (uint32_t s = threadIdx.x; s < nseg; s += blockDim.x) acc = jaci_add(acc, load_jaci(&Tw[s]));
+    for (uint32_t s = threadIdx.x; s < nseg; s += blockDim.x) acc = pti_add(acc, load_pti(&Tw[s]));
   } else {
     const uint32_t half = nseg >> 1;
     const uint32_t lowmask = (1u << k) - 1u;
 #pragma unroll 1
     for (uint32_t j = threadIdx.x; j < half; j += blockDim.x) {
       const uint32_t s = ((j & ~lowmask) << 1) | (1u << k) | (j & lowmask);
-      acc = jaci_add(acc, load_jaci(&Sw[s]));
+      acc = pti_add(acc, load_pti(&Sw[s]));
     }
   }
-  store_jaci(&sh[threadIdx.x], acc);
+  store_pti(&sh[threadIdx.x], acc);
   __syncthreads();
 #pragma unroll 1
   for (uint32_t stride = blockDim.x >> 1; stride >= 1; stride >>= 1) {
     if (threadIdx.x < stride) {
-      const JacI a = load_jaci(&sh[threadIdx.x]);
-      const JacI b2 = load_jaci(&sh[threadIdx.x + stride]);
-      store_jaci(&sh[threadIdx.x], jaci_add(a, b2));
+      const PtI a = load_pti(&sh[threadIdx.x]);
+      const PtI b2 = load_pti(&sh[threadIdx.x + stride]);
+      store_pti(&sh[threadIdx.x], pti_add(a, b2));
     }
     __syncthreads();
   }
   // the host Horner pass works on the external 32-bit-limb form
-  if (threadIdx.x == 0) store_jac(&partial[(size_t)w * (K + 1) + k], jaci_to_ext(load_jaci(&sh[0])));
+  if (threadIdx.x == 0) store_jac(&partial[(size_t)w * (K + 1) + k], pti_to_ext(load_pti(&sh[0])));
 }
 
 int reduce_set_attributes(const char** failed) {
@@ -79,11 +79,11 @@ int reduce_set_attributes(const char** failed) {
   return 0;
 }
 
-void launch_reduce(hipStream_t st, const Plan& p, const JacI* buckets, JacI* S, JacI* T, Jacobian* partial) {
+void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, PtI* S, PtI* T, Jacobian* partial) {
   hipLaunchKernelGGL(reduce_seg_kernel, dim3((unsigned)((p.total_segs + 63) / 64)), dim3(64), 0, st, buckets,
                      (uint32_t)p.total_segs, S, T);
   hipLaunchKernelGGL(reduce_tree_kernel, dim3(p.K + 1, p.W), dim3(p.tree_threads),
-                     p.tree_threads * sizeof(JacI), st, (const JacI*)S, (const JacI*)T, p.nseg, p.K,
+                     p.tree_threads * sizeof(PtI), st, (const PtI*)S, (const PtI*)T, p.nseg, p.K,
                      partial);
 }
 

@@ -197,6 +197,7 @@ size_scan_kernel(uint32_t* __restrict__ size_bins, uint32_t CH, uint32_t* __rest
   if (t == 0) {
     counters->total_items = total;
     counters->multi_count = 0;
+    counters->pad[0] = 0;   // deferred (big) split buckets, see combine_small_kernel
   }
   uint32_t wv = (t < W) ? win_items[t] : 0u;
   uint32_t wtotal;

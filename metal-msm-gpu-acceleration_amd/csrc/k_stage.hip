@@ -148,14 +148,14 @@ ref_accumulate_kernel(const uint2* __restrict__ pairs, size_t n_pairs, const Jac
 // weight d: X[w][d] = B[w][d-1] for 1 <= d <= bs, identity elsewhere.
 __global__ void __launch_bounds__(256)
 pad_buckets_kernel(const Jacobian* __restrict__ in, uint32_t bs, uint32_t W, uint32_t c,
-                   JacI* __restrict__ out) {
+                   PtI* __restrict__ out) {
   const uint32_t nb = 1u << c;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= W * nb) return;
   const uint32_t w = t >> c, d = t & (nb - 1);
   Jacobian v = jac_identity();
   if (d >= 1 && d <= bs) v = load_jac(&in[(size_t)w * bs + d - 1]);
-  store_jaci(&out[t], jaci_from_ext(v));   // production window reduction works on internal limbs
+  store_pti(&out[t], pti_from_ext(v));   // production window reduction works on internal limbs
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -198,7 +198,7 @@ void launch_ref_accumulate(hipStream_t st, const uint2* pairs, size_t n_pairs, c
                      points, n_points, total_buckets, buckets);
 }
 
-void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t c, JacI* out) {
+void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t c, PtI* out) {
   const size_t total = (size_t)W << c;
   hipLaunchKernelGGL(pad_buckets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, bs, W, c, out);
 }

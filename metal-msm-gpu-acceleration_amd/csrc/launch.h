@@ -51,12 +51,12 @@ void launch_be32_to_le(hipStream_t st, const uint32_t* in, size_t words, uint32_
 void launch_ark_affine_to_affine(hipStream_t st, const uint8_t* in, uint32_t n, Affine* out);
 
 // k_accumulate.hip
-void launch_accumulate(hipStream_t st, const Plan& p, const AffI* bases, const SortBuffers& b, JacI* buckets,
-                       JacI* partials);
+void launch_accumulate(hipStream_t st, const Plan& p, const AffI* bases, const SortBuffers& b, PtI* buckets,
+                       PtI* partials);
 
 // k_reduce.hip
 int reduce_set_attributes(const char** failed);
-void launch_reduce(hipStream_t st, const Plan& p, const JacI* buckets, JacI* S, JacI* T, Jacobian* partial);
+void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, PtI* S, PtI* T, Jacobian* partial);
 
 // k_misc.hip
 void launch_projective_to_affine(hipStream_t st, const Jacobian* in, uint32_t n, Affine* out);
@@ -70,7 +70,7 @@ void launch_ref_prepare(hipStream_t st, const u256* scalars, uint32_t n, uint32_
 void launch_radix_sort_pairs(hipStream_t st, uint2* a, uint2* b, size_t n, uint32_t* tile_hist, uint2** result);
 void launch_ref_accumulate(hipStream_t st, const uint2* pairs, size_t n_pairs, const Jacobian* points,
                            uint32_t n_points, uint32_t total_buckets, Jacobian* buckets);
-void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t c, JacI* out);
+void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t c, PtI* out);
 void launch_test_op(hipStream_t st, int op, const u256* a, const u256* b, u256* out, uint32_t count);
 
 }  // namespace msm_amd

@@ -308,13 +308,13 @@ size_t point_bytes(int layout) {
 }
 
 // Window reduction of a production-layout bucket matrix: buckets [W][nb] -> partial [W][K+1] on device.
-int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, const Plan& p, const JacI* buckets) {
+int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, const Plan& p, const PtI* buckets) {
   hipStream_t st = w.stream;
   int rc;
-  if ((rc = ensure(ctx, w.S, p.total_segs * sizeof(JacI)))) return rc;
-  if ((rc = ensure(ctx, w.T, p.total_segs * sizeof(JacI)))) return rc;
+  if ((rc = ensure(ctx, w.S, p.total_segs * sizeof(PtI)))) return rc;
+  if ((rc = ensure(ctx, w.T, p.total_segs * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.partial, p.partial_count * sizeof(Jacobian)))) return rc;
-  launch_reduce(st, p, buckets, (JacI*)w.S.p, (JacI*)w.T.p, (Jacobian*)w.partial.p);
+  launch_reduce(st, p, buckets, (PtI*)w.S.p, (PtI*)w.T.p, (Jacobian*)w.partial.p);
   HIP_TRY(ctx, hipGetLastError());
   return MSM_AMD_OK;
 }
@@ -340,8 +340,8 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   if ((rc = ensure(ctx, w.multi_list, p.max_items * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.counters, sizeof(PlanCounters)))) return rc;
   if ((rc = ensure(ctx, w.bases29, n * sizeof(AffI)))) return rc;
-  if ((rc = ensure(ctx, w.buckets, p.total_buckets * sizeof(JacI)))) return rc;
-  if ((rc = ensure(ctx, w.item_partials, p.max_items * sizeof(JacI)))) return rc;
+  if ((rc = ensure(ctx, w.buckets, p.total_buckets * sizeof(PtI)))) return rc;
+  if ((rc = ensure(ctx, w.item_partials, p.max_items * sizeof(PtI)))) return rc;
   SortBuffers sb{};
   sb.digits = (uint16_t*)w.digits.p;
   sb.counts = (uint32_t*)w.counts.p;
@@ -369,10 +369,10 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   launch_sort(st, p, sb);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_SORT], st));
 
-  launch_accumulate(st, p, (const AffI*)w.bases29.p, sb, (JacI*)w.buckets.p, (JacI*)w.item_partials.p);
+  launch_accumulate(st, p, (const AffI*)w.bases29.p, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
 
-  if ((rc = enqueue_reduce(ctx, w, p, (const JacI*)w.buckets.p))) return rc;
+  if ((rc = enqueue_reduce(ctx, w, p, (const PtI*)w.buckets.p))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial, w.partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_REDUCE], st));
@@ -786,12 +786,12 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   const size_t in_bytes = (size_t)buckets_size * num_windows * 96;
   if ((rc = ensure(ctx, ctx->scratch_a, in_bytes))) return rc;
   if ((rc = ensure(ctx, ctx->scratch_b, in_bytes))) return rc;
-  if ((rc = ensure(ctx, ctx->ws[0].buckets, p.total_buckets * sizeof(JacI)))) return rc;
+  if ((rc = ensure(ctx, ctx->ws[0].buckets, p.total_buckets * sizeof(PtI)))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, buckets_be32, in_bytes, hipMemcpyHostToDevice, st));
   const size_t words = (size_t)buckets_size * num_windows * 3;
   launch_be32_to_le(st, (const uint32_t*)ctx->scratch_a.p, words, (uint32_t*)ctx->scratch_b.p);
-  launch_pad_buckets(st, (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.c, (JacI*)ctx->ws[0].buckets.p);
-  if ((rc = enqueue_reduce(ctx, ctx->ws[0], p, (const JacI*)ctx->ws[0].buckets.p))) return rc;
+  launch_pad_buckets(st, (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.c, (PtI*)ctx->ws[0].buckets.p);
+  if ((rc = enqueue_reduce(ctx, ctx->ws[0], p, (const PtI*)ctx->ws[0].buckets.p))) return rc;
   std::vector<Jacobian> partial(p.partial_count);
   HIP_TRY(ctx, hipMemcpyAsync(partial.data(), ctx->ws[0].partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, st));

@@ -68,34 +68,34 @@ MSM_HD void run_test_op(int op, const u256* a, const u256* b, u256* out, uint32_
     r = jac_double(p);
   } else if (op == 22) {   // internal representation: Jacobian + affine (b given with z = one or z = 0)
     const Jacobian q = pb[t];
-    const JacI pi = jaci_from_ext(p);
+    const PtI pi = pti_from_ext(p);
     if (jac_is_identity(q)) {
-      r = jaci_to_ext(pi);
+      r = pti_to_ext(pi);
     } else {
       Affine qa;
       qa.x = q.x;
       qa.y = q.y;
       const AffI qi = affi_from_ext(qa);
-      r = jaci_to_ext(jaci_is_identity(pi) ? jaci_from_affi(qi) : jaci_madd(pi, qi));
+      r = pti_to_ext(pti_is_identity(pi) ? pti_from_affi(qi) : pti_madd(pi, qi));
     }
   } else if (op == 23) {   // internal representation: Jacobian + Jacobian
-    r = jaci_to_ext(jaci_add(jaci_from_ext(p), jaci_from_ext(pb[t])));
+    r = pti_to_ext(pti_add(pti_from_ext(p), pti_from_ext(pb[t])));
   } else if (op == 24) {   // 64 chained mixed additions without leaving the lazy internal form: p + 64 q
     const Jacobian q = pb[t];
-    JacI acc = jaci_from_ext(p);
+    PtI acc = pti_from_ext(p);
     if (!jac_is_identity(q)) {
       Affine qa;
       qa.x = q.x;
       qa.y = q.y;
       const AffI qi = affi_from_ext(qa);
-      for (int i = 0; i < 64; ++i) acc = jaci_is_identity(acc) ? jaci_from_affi(qi) : jaci_madd(acc, qi);
+      for (int i = 0; i < 64; ++i) acc = pti_is_identity(acc) ? pti_from_affi(qi) : pti_madd(acc, qi);
     }
-    r = jaci_to_ext(acc);
+    r = pti_to_ext(acc);
   } else if (op == 25) {   // 16 chained full additions: p + 16 q with q Jacobian
-    const JacI qi = jaci_from_ext(pb[t]);
-    JacI acc = jaci_from_ext(p);
-    for (int i = 0; i < 16; ++i) acc = jaci_add(acc, qi);
-    r = jaci_to_ext(acc);
+    const PtI qi = pti_from_ext(pb[t]);
+    PtI acc = pti_from_ext(p);
+    for (int i = 0; i < 16; ++i) acc = pti_add(acc, qi);
+    r = pti_to_ext(acc);
   }
   po[t] = r;
 }

@@ -24,12 +24,12 @@ __global__ void __launch_bounds__(256) k_op(const u256* in, u256* out) {
   } else {
     Affine qa; qa.x = xe; qa.y = ye;           // not a curve point: timing only (no exceptional paths taken)
     const AffI q = affi_from_ext(qa);
-    JacI acc = jaci_from_affi(q);
+    PtI acc = pti_from_affi(q);
     acc.x = Fq29::from_ext(ye);
 #pragma unroll 1
     for (int i = 0; i < ITER; ++i) {
-      if (VARIANT == 4) acc = jaci_madd(acc, q);
-      if (VARIANT == 5) acc = jaci_add_nz(acc, acc);
+      if (VARIANT == 4) acc = pti_madd(acc, q);
+      if (VARIANT == 5) acc = pti_add_nz(acc, acc);
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = Fq29::to_ext(acc.x);
   }
@@ -62,7 +62,7 @@ int main() {
   run<1>("Fq29::sqr", din, dout, cus);
   run<2>("Fq29::sub+norm", din, dout, cus);
   run<3>("Fq29::add+norm", din, dout, cus);
-  run<4>("jaci_madd", din, dout, cus);
-  run<5>("jaci_add_nz", din, dout, cus);
+  run<4>("pti_madd", din, dout, cus);
+  run<5>("pti_add_nz", din, dout, cus);
   return 0;
 }
