@@ -99,6 +99,9 @@ struct Fq29 {
     return r;
   }
 
+  // -a (mod p) for a with limbs <= 2^30 - 2 and value < ~3.9 p; result < 4 p, limbs 0..7 < 2^29 + 8.
+  MSM_HD static fe29 neg(const fe29& a) { return norm(sub<K4E30>(zero(), a)); }
+
   // One parallel carry round: limbs 0..7 < 2^29 + 8 afterwards, limb 8 absorbs the top carry.
   MSM_HD static fe29 norm(const fe29& a) {
     fe29 r;

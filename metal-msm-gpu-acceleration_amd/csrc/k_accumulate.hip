@@ -19,12 +19,12 @@ accumulate_kernel(const AffI* __restrict__ bases, const uint32_t* __restrict__ s
                   const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
                   const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
                   const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
-                  uint32_t c, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
+                  uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= counters->total_items) return;
   const uint2 it = order[slot];
   const uint32_t b = it.x, j = it.y;
-  const uint32_t w = b >> c;
+  const uint32_t w = b >> lb;
   const uint32_t size = bucket_size[b];
   const uint32_t lo = j * CH;
   const uint32_t cnt = min(size - lo, CH);
@@ -35,13 +35,20 @@ accumulate_kernel(const AffI* __restrict__ bases, const uint32_t* __restrict__ s
   for (uint32_t i = 0; i < cnt; ++i) {
     // the gather of this point is issued here and first consumed after the Z1^2 squaring inside pti_madd,
     // which hides most of its latency; only the next index is prefetched (one register, not a whole point)
-    const AffI cur = load_affi(&bases[next_idx]);
+    AffI cur = load_affi(&bases[next_idx & 0x7FFFFFFFu]);
+    const bool cur_is_id = affi_is_identity(cur);
+    const bool negate = (next_idx >> 31) != 0;   // negative digit: add -P (signed digits, see digits_kernel)
     if (i + 1 < cnt) next_idx = idx[i + 1];
+    {
+      const fe29 ny = Fq29::neg(cur.y);
+#pragma unroll
+      for (int l = 0; l < 9; ++l) cur.y.l[l] = negate ? ny.l[l] : cur.y.l[l];
+    }
     if (pti_is_identity(acc)) {
-      if (!affi_is_identity(cur)) acc = pti_from_affi(cur);
+      if (!cur_is_id) acc = pti_from_affi(cur);
     } else {
       const PtI sum = pti_madd(acc, cur);
-      if (!affi_is_identity(cur)) acc = sum;
+      if (!cur_is_id) acc = sum;
     }
   }
   if (size <= CH) {
@@ -62,14 +69,14 @@ constexpr uint32_t kSerialItems = 8;
 __global__ void __launch_bounds__(64)
 combine_small_kernel(const uint32_t* __restrict__ multi_list, PlanCounters* __restrict__ counters,
                      const uint32_t* __restrict__ bucket_size, const uint32_t* __restrict__ item_start,
-                     const uint32_t* __restrict__ win_base, uint32_t c, uint32_t CH,
+                     const uint32_t* __restrict__ win_base, uint32_t lb, uint32_t CH,
                      const PtI* __restrict__ partials, PtI* __restrict__ buckets, uint32_t* __restrict__ big_list) {
   const uint32_t count = counters->multi_count;
   for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < count; m += gridDim.x * blockDim.x) {
     const uint32_t b = multi_list[m];
     const uint32_t nitems = (bucket_size[b] + CH - 1) / CH;
     if (nitems <= kSerialItems) {
-      const PtI* src = partials + (size_t)win_base[b >> c] + item_start[b];
+      const PtI* src = partials + (size_t)win_base[b >> lb] + item_start[b];
       PtI acc = load_pti(&src[0]);
 #pragma unroll 1
       for (uint32_t i = 1; i < nitems; ++i) acc = pti_add(acc, load_pti(&src[i]));
@@ -83,14 +90,14 @@ combine_small_kernel(const uint32_t* __restrict__ multi_list, PlanCounters* __re
 __global__ void __launch_bounds__(64)
 combine_big_kernel(const uint32_t* __restrict__ big_list, const PlanCounters* __restrict__ counters,
                    const uint32_t* __restrict__ bucket_size, const uint32_t* __restrict__ item_start,
-                   const uint32_t* __restrict__ win_base, uint32_t c, uint32_t CH,
+                   const uint32_t* __restrict__ win_base, uint32_t lb, uint32_t CH,
                    const PtI* __restrict__ partials, PtI* __restrict__ buckets) {
   __shared__ PtI sh[64];
   const uint32_t count = counters->pad[0];
   for (uint32_t m = blockIdx.x; m < count; m += gridDim.x) {
     const uint32_t b = big_list[m];
     const uint32_t nitems = (bucket_size[b] + CH - 1) / CH;
-    const PtI* src = partials + (size_t)win_base[b >> c] + item_start[b];
+    const PtI* src = partials + (size_t)win_base[b >> lb] + item_start[b];
     PtI acc = pti_identity();
 #pragma unroll 1
     for (uint32_t i = threadIdx.x; i < nitems; i += 64) acc = pti_add(acc, load_pti(&src[i]));
@@ -117,16 +124,17 @@ void launch_accumulate(hipStream_t st, const Plan& p, const AffI* bases, const S
   hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((p.max_items + 63) / 64)), dim3(64), 0, st, bases,
                      (const uint32_t*)b.sorted, (const uint32_t*)b.bucket_start, (const uint32_t*)b.bucket_size,
                      (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, (const uint2*)b.order,
-                     (const PlanCounters*)b.counters, p.n, p.c, p.CH, buckets, partials);
+                     (const PlanCounters*)b.counters, p.n, p.lb, p.CH, buckets, partials);
   // multi_list doubles as big_list storage: its second half (entries max_items/2 ..) is free because a split
   // bucket accounts for at least two items
   uint32_t* big_list = b.multi_list + p.max_items / 2 + 1;
-  hipLaunchKernelGGL(combine_small_kernel, dim3(256), dim3(64), 0, st, (const uint32_t*)b.multi_list, b.counters,
-                     (const uint32_t*)b.bucket_size, (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, p.c,
+  // one lane per possibly-split bucket: at most one split bucket per two items
+  hipLaunchKernelGGL(combine_small_kernel, dim3((unsigned)((p.max_items / 2 + 63) / 64)), dim3(64), 0, st, (const uint32_t*)b.multi_list, b.counters,
+                     (const uint32_t*)b.bucket_size, (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, p.lb,
                      p.CH, (const PtI*)partials, buckets, big_list);
   hipLaunchKernelGGL(combine_big_kernel, dim3(512), dim3(64), 0, st, (const uint32_t*)big_list,
                      (const PlanCounters*)b.counters, (const uint32_t*)b.bucket_size, (const uint32_t*)b.item_start,
-                     (const uint32_t*)b.win_items, p.c, p.CH, (const PtI*)partials, buckets);
+                     (const uint32_t*)b.win_items, p.lb, p.CH, (const PtI*)partials, buckets);
 }
 
 }  // namespace msm_amd

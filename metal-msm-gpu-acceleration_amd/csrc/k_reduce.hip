@@ -5,9 +5,9 @@
 namespace msm_amd {
 
 // ------------------------------------------------------------------------------------------------
-// Stage 4a: per-segment running sums.  For segment s of window w (buckets d = 8s .. 8s+7):
-//   S[w][s] = sum_j X[8s+j]          T[w][s] = sum_j j * X[8s+j]
-// so that  sum_d d*X[d] = sum_s T[s] + 8 * sum_s s*S[s].   Replaces sum_reduction_partial
+// Stage 4a: per-segment running sums.  Slot i of a window holds the bucket of digit magnitude i + 1.  For
+// segment s (slots 8s .. 8s+7):   S[w][s] = sum_j X[8s+j]     T[w][s] = sum_j j * X[8s+j]
+// so that  sum_i (i+1) X[i] = sum_s (T[s] + S[s]) + 8 * sum_s s*S[s].   Replaces sum_reduction_partial
 // (msm.h.metal:319-461), whose combine step needs a scalar multiplication per merge.
 __global__ void __launch_bounds__(64)
 reduce_seg_kernel(const PtI* __restrict__ buckets, uint32_t total_segs,
@@ -28,7 +28,7 @@ reduce_seg_kernel(const PtI* __restrict__ buckets, uint32_t total_segs,
 
 // Stage 4b: tree sums.  grid = (K + 1, W) with K = c - 3 bits of segment index; block = tree_threads
 // (power of two, 64..1024); dynamic LDS = tree_threads * 144 bytes.
-//   blockIdx.x == K : partial[w][K] = sum_s T[w][s]
+//   blockIdx.x == K : partial[w][K] = sum_s (T[w][s] + S[w][s])
 //   blockIdx.x  < K : partial[w][k] = sum over segments s with bit k set of S[w][s]
 // The host then evaluates  W_w = partial[w][K] + 8 * sum_k 2^k partial[w][k]  inside one Horner pass
 // over all bit positions (replaces sum_reduction_final msm.h.metal:463-562 and the doublings of
@@ -43,8 +43,12 @@ reduce_tree_kernel(const PtI* __restrict__ S, const PtI* __restrict__ T, uint32_
   const PtI* Tw = T + (size_t)w * nseg;
   PtI acc = pti_identity();
   if (k == K) {
+    // slot i carries weight i + 1:  sum_i (i+1) X[i] = sum_s T[s] + sum_s S[s] + 8 sum_s s S[s]
 #pragma unroll 1
-    for (uint32_t s = threadIdx.x; s < nseg; s += blockDim.x) acc = pti_add(acc, load_pti(&Tw[s]));
+    for (uint32_t s = threadIdx.x; s < nseg; s += blockDim.x) {
+      acc = pti_add(acc, load_pti(&Tw[s]));
+      acc = pti_add(acc, load_pti(&Sw[s]));
+    }
   } else {
     const uint32_t half = nseg >> 1;
     const uint32_t lowmask = (1u << k) - 1u;

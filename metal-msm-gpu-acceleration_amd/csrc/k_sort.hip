@@ -8,10 +8,13 @@ namespace msm_amd {
 constexpr int kSortThreads = 1024;       // hist / plan / scatter workgroup size
 
 // ------------------------------------------------------------------------------------------------
-// Stage 1: digit extraction.  Replaces kernel prepare_buckets_indices (msm.h.metal:17-59, one thread
-// per threadgroup and a generic 256-bit shift per window) and the CPU de-Montgomery of scalars
-// (limbs_conversion.rs:282-288).  scalars_mont: 1 = host Montgomery form (bn256::Fr / ark Fr memory),
-// 0 = canonical integer.
+// Stage 1: signed digit extraction.  k = sum_w d_w 2^(c w) with d_w in (-2^(c-1), 2^(c-1)]: a raw window value
+// v (plus the carry of the window below) above 2^(c-1) becomes v - 2^c with a carry into the next window, so
+// only 2^(c-1) bucket magnitudes exist per window -- half the buckets of the reference's unsigned digits
+// (kernel prepare_buckets_indices, msm.h.metal:17-59) for the window reduction to fold.  A negative digit adds
+// -P, which costs one field negation of y.  Output per (window, point): u16 = sign << 15 | magnitude
+// (magnitude 0 = no contribution).  scalars_mont: 1 = host Montgomery form (bn256::Fr / ark Fr memory; the
+// reference de-Montgomerys on the CPU, limbs_conversion.rs:282-288), 0 = canonical integer.
 __global__ void __launch_bounds__(256)
 digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W, int scalars_mont,
               uint16_t* __restrict__ digits) {
@@ -19,9 +22,19 @@ digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t
   if (t >= n) return;
   u256 k = load_u256(&scalars[t]);
   if (scalars_mont) k = Fr::from_mont(k);
+  const uint32_t half = 1u << (c - 1);
+  uint32_t carry = 0;
   for (uint32_t w = 0; w < W; ++w) {
-    const uint32_t d = u256_extract_bits(k, w * c, c);
-    digits[(size_t)w * n + t] = (uint16_t)d;
+    const uint32_t start = w * c;
+    uint32_t v = (start < 256 ? u256_extract_bits(k, start, c) : 0u) + carry;
+    uint32_t neg = 0;
+    carry = 0;
+    if (v > half) {
+      v = (1u << c) - v;
+      neg = 1;
+      carry = 1;
+    }
+    digits[(size_t)w * n + t] = (uint16_t)(v | (neg << 15));
   }
 }
 
@@ -29,10 +42,10 @@ digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t
 // Stage 2a: LDS histogram of one chunk of one window.  grid = (Q, W), block = kSortThreads,
 // dynamic LDS = nb * 4 bytes.
 __global__ void __launch_bounds__(kSortThreads)
-hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t c, uint32_t chunk,
+hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t lb, uint32_t chunk,
             uint32_t* __restrict__ counts) {
   extern __shared__ uint32_t lds_u32[];
-  const uint32_t nb = 1u << c;
+  const uint32_t nb = 1u << lb;
   const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
   for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lds_u32[i] = 0;
   __syncthreads();
@@ -40,8 +53,8 @@ hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t c, uint32_
   const uint32_t hi = min(n, lo + chunk);
   const uint16_t* dw = digits + (size_t)w * n;
   for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
-    const uint32_t d = dw[t];
-    if (d) atomicAdd(&lds_u32[d], 1u);
+    const uint32_t m = dw[t] & 0x7FFFu;   // magnitude; slot m - 1
+    if (m) atomicAdd(&lds_u32[m - 1], 1u);
   }
   __syncthreads();
   uint32_t* out = counts + ((size_t)w * Q + q) * nb;
@@ -51,12 +64,12 @@ hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t c, uint32_
 // Stage 2b: per-bucket totals.  One thread per (window, digit): turns counts[w][q][d] into the exclusive
 // prefix over chunks q (position of chunk q's first element inside the bucket) and writes the bucket size.
 __global__ void __launch_bounds__(256)
-chunk_prefix_kernel(uint32_t* __restrict__ counts, uint32_t c, uint32_t Q, uint32_t W,
+chunk_prefix_kernel(uint32_t* __restrict__ counts, uint32_t lb, uint32_t Q, uint32_t W,
                     uint32_t* __restrict__ bucket_size) {
-  const uint32_t nb = 1u << c;
+  const uint32_t nb = 1u << lb;
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= W * nb) return;
-  const uint32_t w = b >> c, d = b & (nb - 1);
+  const uint32_t w = b >> lb, d = b & (nb - 1);
   uint32_t* cw = counts + (size_t)w * Q * nb + d;
   uint32_t run = 0;
   for (uint32_t q = 0; q < Q; ++q) {
@@ -97,11 +110,11 @@ __device__ __forceinline__ uint32_t window_scan_lds(uint32_t* tot, uint32_t* scr
 }
 
 __global__ void __launch_bounds__(kSortThreads)
-plan_kernel(const uint32_t* __restrict__ bucket_size, uint32_t c, uint32_t CH,
+plan_kernel(const uint32_t* __restrict__ bucket_size, uint32_t lb, uint32_t CH,
             uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ item_start,
             uint32_t* __restrict__ win_items) {
   extern __shared__ uint32_t lds_u32[];
-  const uint32_t nb = 1u << c;
+  const uint32_t nb = 1u << lb;
   const uint32_t w = blockIdx.x;
   uint32_t* tot = lds_u32;                               // skewed: index i lives at i + (i >> 5)
   uint32_t* scratch = lds_u32 + nb + (nb >> 5) + 1;      // 17 words
@@ -122,11 +135,11 @@ plan_kernel(const uint32_t* __restrict__ bucket_size, uint32_t c, uint32_t CH,
 // Order inside a bucket is unspecified (LDS atomic arrival order), exactly as the reference allows
 // (sort_buckets.rs:111-125 checks only multiset + non-decreasing keys).
 __global__ void __launch_bounds__(kSortThreads)
-scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t c, uint32_t chunk,
+scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t lb, uint32_t chunk,
                const uint32_t* __restrict__ chunk_prefix, const uint32_t* __restrict__ bucket_start,
                uint32_t* __restrict__ sorted) {
   extern __shared__ uint32_t lds_u32[];
-  const uint32_t nb = 1u << c;
+  const uint32_t nb = 1u << lb;
   const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
   const uint32_t* rel = chunk_prefix + ((size_t)w * Q + q) * nb;
   const uint32_t* bs = bucket_start + (size_t)w * nb;
@@ -137,10 +150,11 @@ scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t c, uint
   const uint16_t* dw = digits + (size_t)w * n;
   uint32_t* sw = sorted + (size_t)w * n;
   for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
-    const uint32_t d = dw[t];
-    if (d) {
-      const uint32_t pos = atomicAdd(&lds_u32[d], 1u);
-      sw[pos] = t;
+    const uint32_t v = dw[t];
+    const uint32_t m = v & 0x7FFFu;
+    if (m) {
+      const uint32_t pos = atomicAdd(&lds_u32[m - 1], 1u);
+      sw[pos] = t | ((v >> 15) << 31);   // bit 31: the digit is negative, add -P
     }
   }
 }
@@ -276,8 +290,8 @@ be32_to_le_kernel(const uint32_t* __restrict__ in, size_t words, uint32_t* __res
 
 
 // ------------------------------------------------------------------------------------------------
-static size_t lds_hist_bytes(uint32_t c) { return (size_t)(1u << c) * 4; }
-static size_t lds_plan_bytes(uint32_t c) { return ((size_t)(1u << c) + ((1u << c) >> 5) + 33) * 4; }
+static size_t lds_hist_bytes(uint32_t lb) { return (size_t)(1u << lb) * 4; }
+static size_t lds_plan_bytes(uint32_t lb) { return ((size_t)(1u << lb) + ((1u << lb) >> 5) + 33) * 4; }
 
 int sort_set_attributes(const char** failed) {
   const int max_lds = 160 * 1024;
@@ -300,14 +314,14 @@ void launch_digits(hipStream_t st, const Plan& p, const u256* scalars, int scala
 }
 
 void launch_sort(hipStream_t st, const Plan& p, const SortBuffers& b) {
-  hipLaunchKernelGGL(hist_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.c), st,
-                     (const uint16_t*)b.digits, p.n, p.c, p.chunk, b.counts);
+  hipLaunchKernelGGL(hist_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.lb), st,
+                     (const uint16_t*)b.digits, p.n, p.lb, p.chunk, b.counts);
   hipLaunchKernelGGL(chunk_prefix_kernel, dim3((unsigned)((p.total_buckets + 255) / 256)), dim3(256), 0, st,
-                     b.counts, p.c, p.Q, p.W, b.bucket_size);
-  hipLaunchKernelGGL(plan_kernel, dim3(p.W), dim3(kSortThreads), lds_plan_bytes(p.c), st,
-                     (const uint32_t*)b.bucket_size, p.c, p.CH, b.bucket_start, b.item_start, b.win_items);
-  hipLaunchKernelGGL(scatter_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.c), st,
-                     (const uint16_t*)b.digits, p.n, p.c, p.chunk, (const uint32_t*)b.counts,
+                     b.counts, p.lb, p.Q, p.W, b.bucket_size);
+  hipLaunchKernelGGL(plan_kernel, dim3(p.W), dim3(kSortThreads), lds_plan_bytes(p.lb), st,
+                     (const uint32_t*)b.bucket_size, p.lb, p.CH, b.bucket_start, b.item_start, b.win_items);
+  hipLaunchKernelGGL(scatter_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.lb), st,
+                     (const uint16_t*)b.digits, p.n, p.lb, p.chunk, (const uint32_t*)b.counts,
                      (const uint32_t*)b.bucket_start, b.sorted);
   (void)hipMemsetAsync(b.size_bins, 0, (p.CH + 1) * sizeof(uint32_t), st);
   const unsigned gb = (unsigned)((p.total_buckets + kSizeThreads - 1) / kSizeThreads);

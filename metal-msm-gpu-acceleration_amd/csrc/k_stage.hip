@@ -144,17 +144,17 @@ ref_accumulate_kernel(const uint2* __restrict__ pairs, size_t n_pairs, const Jac
   store_jac(&buckets[key], acc);
 }
 
-// Reference bucket matrix [W][bs] (weight of column b is b+1) -> production layout [W][nb], entry d has
-// weight d: X[w][d] = B[w][d-1] for 1 <= d <= bs, identity elsewhere.
+// Reference bucket matrix [W][bs] (column b has weight b+1) -> production layout [W][nb], nb = 2^lb >= bs,
+// slot i has weight i + 1: a plain copy with identity padding and conversion to the internal limbs.
 __global__ void __launch_bounds__(256)
-pad_buckets_kernel(const Jacobian* __restrict__ in, uint32_t bs, uint32_t W, uint32_t c,
+pad_buckets_kernel(const Jacobian* __restrict__ in, uint32_t bs, uint32_t W, uint32_t lb,
                    PtI* __restrict__ out) {
-  const uint32_t nb = 1u << c;
+  const uint32_t nb = 1u << lb;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= W * nb) return;
-  const uint32_t w = t >> c, d = t & (nb - 1);
+  const uint32_t w = t >> lb, d = t & (nb - 1);
   Jacobian v = jac_identity();
-  if (d >= 1 && d <= bs) v = load_jac(&in[(size_t)w * bs + d - 1]);
+  if (d < bs) v = load_jac(&in[(size_t)w * bs + d]);
   store_pti(&out[t], pti_from_ext(v));   // production window reduction works on internal limbs
 }
 
@@ -198,9 +198,9 @@ void launch_ref_accumulate(hipStream_t st, const uint2* pairs, size_t n_pairs, c
                      points, n_points, total_buckets, buckets);
 }
 
-void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t c, PtI* out) {
-  const size_t total = (size_t)W << c;
-  hipLaunchKernelGGL(pad_buckets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, bs, W, c, out);
+void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t lb, PtI* out) {
+  const size_t total = (size_t)W << lb;
+  hipLaunchKernelGGL(pad_buckets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, bs, W, lb, out);
 }
 
 void launch_test_op(hipStream_t st, int op, const u256* a, const u256* b, u256* out, uint32_t count) {

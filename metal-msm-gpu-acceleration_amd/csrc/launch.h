@@ -14,10 +14,11 @@ constexpr int kSeg = 1 << kSegLog;
 
 // Geometry of one MSM (see make_plan in msm_host.hip).
 struct Plan {
-  uint32_t n, c, W, nb;       // points, window bits, windows, digit values per window (2^c)
+  uint32_t n, c, W;           // points, window bits, windows (signed digits: W = floor(254/c) + 1)
+  uint32_t lb, nb;            // bucket slots per window nb = 2^lb = max(2^(c-1), 8); slot i holds |digit| = i + 1
   uint32_t Q, chunk;          // sort: chunks per window, points per chunk
   uint32_t CH;                // accumulate: max points per work item (bucket chunk)
-  uint32_t nseg, K;           // reduce: segments per window, bits of segment index (c - 3)
+  uint32_t nseg, K;           // reduce: segments per window, bits of segment index (lb - 3)
   uint32_t tree_threads;
   size_t total_buckets, total_segs, partial_count, max_items;
 };
@@ -70,7 +71,7 @@ void launch_ref_prepare(hipStream_t st, const u256* scalars, uint32_t n, uint32_
 void launch_radix_sort_pairs(hipStream_t st, uint2* a, uint2* b, size_t n, uint32_t* tile_hist, uint2** result);
 void launch_ref_accumulate(hipStream_t st, const uint2* pairs, size_t n_pairs, const Jacobian* points,
                            uint32_t n_points, uint32_t total_buckets, Jacobian* buckets);
-void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t c, PtI* out);
+void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t lb, PtI* out);
 void launch_test_op(hipStream_t st, int op, const u256* a, const u256* b, u256* out, uint32_t count);
 
 }  // namespace msm_amd

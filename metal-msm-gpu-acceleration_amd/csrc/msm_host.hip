@@ -119,22 +119,28 @@ Plan make_plan(size_t n, uint32_t c) {
   Plan p{};
   p.n = (uint32_t)n;
   p.c = c;
-  p.W = (kModulusBits + c - 1) / c;   // window starts 0, c, 2c, ... < 254 (msm.rs:143-146)
-  p.nb = 1u << c;
+  p.W = kModulusBits / c + 1;         // signed digits: the top window absorbs the last carry (= ceil(255 / c))
+  p.lb = std::max(c - 1, (uint32_t)kSegLog);
+  p.nb = 1u << p.lb;                  // slot i <-> digit magnitude i + 1 (c = 3 is padded to 8 slots)
   // one 1024-thread workgroup (whole-window LDS histogram) per (chunk, window): aim at ~1 per CU
   uint32_t Q = std::max(1u, 256u / p.W);
   const uint32_t max_q = (uint32_t)((n + 4095) / 4096);
   Q = std::max(1u, std::min(Q, max_q));
   p.Q = Q;
   p.chunk = (uint32_t)((n + Q - 1) / Q);
-  // accumulate work items: at most CH points each; CH = 4 x the mean bucket population (so that
-  // uniformly distributed digits never split a bucket), power of two, 64..512
-  uint32_t ch = 64;
-  const size_t mean = std::max<size_t>(1, n >> c);
-  while (ch < 512 && ch < 4 * mean) ch <<= 1;
+  // accumulate work items: at most CH points each.  The accumulate kernel wants >= ~400 k items (two full
+  // rounds of 3 waves/SIMD on 1024 SIMDs) so that the chip stays full until the end; buckets longer than CH
+  // are cut into several items whose partial sums the combine kernels add up (one extra addition per cut).
+  uint32_t ch = 16;
+  const size_t target_len = ((size_t)p.W * n) / 393216;
+  while (ch < 512 && (size_t)ch * 2 <= target_len) ch <<= 1;
+  if (const char* e = std::getenv("MSM_AMD_CH")) {
+    const int v = std::atoi(e);
+    if (v >= 16 && v <= 512 && (v & (v - 1)) == 0) ch = (uint32_t)v;
+  }
   p.CH = ch;
   p.nseg = p.nb >> kSegLog;
-  p.K = c - kSegLog;
+  p.K = p.lb - kSegLog;
   p.total_buckets = (size_t)p.W * p.nb;
   p.total_segs = (size_t)p.W * p.nseg;
   p.partial_count = (size_t)p.W * (p.K + 1);
@@ -146,13 +152,14 @@ Plan make_plan(size_t n, uint32_t c) {
 }
 
 // Geometry of the window reduction alone (stage entry point sum_reduction).
-Plan make_reduce_plan(uint32_t c, uint32_t W) {
+Plan make_reduce_plan(uint32_t lb, uint32_t W) {
   Plan p{};
-  p.c = c;
+  p.c = lb + kSegLog + 1;   // only used to space bit positions in host_combine (one window at a time)
   p.W = W;
-  p.nb = 1u << c;
+  p.lb = lb;
+  p.nb = 1u << lb;
   p.nseg = p.nb >> kSegLog;
-  p.K = c - kSegLog;
+  p.K = lb - kSegLog;
   p.total_buckets = (size_t)p.W * p.nb;
   p.total_segs = (size_t)p.W * p.nseg;
   p.partial_count = (size_t)p.W * (p.K + 1);
@@ -195,7 +202,7 @@ Jacobian normalise(const Jacobian& p) {
   return r;
 }
 
-// Window value  W_w = partial[w][K] + 8 * sum_k 2^k * partial[w][k]   and the final Horner
+// Window value  W_w = partial[w][K] + 8 * sum_k 2^k * partial[w][k]  (partial[w][K] = sum T + sum S) and the final Horner
 // sum_w 2^(c*w) W_w, fused into ONE pass over bit positions: term partial[w][K] sits at bit c*w,
 // partial[w][k] at bit c*w + 3 + k.  Replaces sum_reduction_final + final_accumulation.rs:19-39.
 Jacobian host_combine(const Jacobian* partial, const Plan& p) {
@@ -774,9 +781,9 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
                           uint32_t num_windows, uint32_t* res_out) {
   if (!ctx || !buckets_be32 || !res_out || buckets_size == 0 || num_windows == 0)
     return fail(ctx, MSM_AMD_INPUT_ERROR, "bad sum_reduction arguments");
-  // production layout needs nb = 2^c > buckets_size (index d carries weight d, d = 0 unused)
+  // production layout: nb = 2^lb >= buckets_size slots per window, slot i carries weight i + 1
   uint32_t c = kSegLog;
-  while ((1u << c) <= buckets_size) ++c;
+  while ((1u << c) < buckets_size) ++c;
   if (c > 24) return fail(ctx, MSM_AMD_INPUT_ERROR, "buckets_size too large");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -790,7 +797,7 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, buckets_be32, in_bytes, hipMemcpyHostToDevice, st));
   const size_t words = (size_t)buckets_size * num_windows * 3;
   launch_be32_to_le(st, (const uint32_t*)ctx->scratch_a.p, words, (uint32_t*)ctx->scratch_b.p);
-  launch_pad_buckets(st, (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.c, (PtI*)ctx->ws[0].buckets.p);
+  launch_pad_buckets(st, (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.lb, (PtI*)ctx->ws[0].buckets.p);
   if ((rc = enqueue_reduce(ctx, ctx->ws[0], p, (const PtI*)ctx->ws[0].buckets.p))) return rc;
   std::vector<Jacobian> partial(p.partial_count);
   HIP_TRY(ctx, hipMemcpyAsync(partial.data(), ctx->ws[0].partial.p, p.partial_count * sizeof(Jacobian),
