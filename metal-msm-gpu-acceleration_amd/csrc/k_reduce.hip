@@ -26,14 +26,14 @@ reduce_seg_kernel(const PtI* __restrict__ buckets, uint32_t total_segs,
   store_pti(&T[s], sos);
 }
 
-// Stage 4b: tree sums.  grid = (K + 1, W) with K = c - 3 bits of segment index; block = tree_threads
-// (power of two, 64..1024); dynamic LDS = tree_threads * 144 bytes.
-//   blockIdx.x == K : partial[w][K] = sum_s (T[w][s] + S[w][s])
+// Stage 4b: tree sums.  grid = (K + 2, W) with K = lb - 3 bits of segment index; block = tree_threads
+// (power of two, 64..512); dynamic LDS = tree_threads * 144 bytes.
+//   blockIdx.x == K : partial[w][K] = sum_s T[w][s]        blockIdx.x == K + 1 : partial[w][K+1] = sum_s S[w][s]
 //   blockIdx.x  < K : partial[w][k] = sum over segments s with bit k set of S[w][s]
 // The host then evaluates  W_w = partial[w][K] + 8 * sum_k 2^k partial[w][k]  inside one Horner pass
 // over all bit positions (replaces sum_reduction_final msm.h.metal:463-562 and the doublings of
 // final_accumulation.rs:19-39).
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(512)
 reduce_tree_kernel(const PtI* __restrict__ S, const PtI* __restrict__ T, uint32_t nseg,
                    uint32_t K, Jacobian* __restrict__ partial) {
   extern __shared__ uint32_t lds_u32[];
@@ -42,13 +42,12 @@ reduce_tree_kernel(const PtI* __restrict__ S, const PtI* __restrict__ T, uint32_
   const PtI* Sw = S + (size_t)w * nseg;
   const PtI* Tw = T + (size_t)w * nseg;
   PtI acc = pti_identity();
-  if (k == K) {
-    // slot i carries weight i + 1:  sum_i (i+1) X[i] = sum_s T[s] + sum_s S[s] + 8 sum_s s S[s]
+  if (k >= K) {
+    // slot i carries weight i + 1:  sum_i (i+1) X[i] = sum_s T[s] + sum_s S[s] + 8 sum_s s S[s];
+    // the two plain sums get a workgroup each (k == K: T, k == K + 1: S) to keep the critical path short
+    const PtI* src = (k == K) ? Tw : Sw;
 #pragma unroll 1
-    for (uint32_t s = threadIdx.x; s < nseg; s += blockDim.x) {
-      acc = pti_add(acc, load_pti(&Tw[s]));
-      acc = pti_add(acc, load_pti(&Sw[s]));
-    }
+    for (uint32_t s = threadIdx.x; s < nseg; s += blockDim.x) acc = pti_add(acc, load_pti(&src[s]));
   } else {
     const uint32_t half = nseg >> 1;
     const uint32_t lowmask = (1u << k) - 1u;
@@ -70,7 +69,7 @@ reduce_tree_kernel(const PtI* __restrict__ S, const PtI* __restrict__ T, uint32_
     __syncthreads();
   }
   // the host Horner pass works on the external 32-bit-limb form
-  if (threadIdx.x == 0) store_jac(&partial[(size_t)w * (K + 1) + k], pti_to_ext(load_pti(&sh[0])));
+  if (threadIdx.x == 0) store_jac(&partial[(size_t)w * (K + 2) + k], pti_to_ext(load_pti(&sh[0])));
 }
 
 int reduce_set_attributes(const char** failed) {
@@ -86,7 +85,7 @@ int reduce_set_attributes(const char** failed) {
 void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, PtI* S, PtI* T, Jacobian* partial) {
   hipLaunchKernelGGL(reduce_seg_kernel, dim3((unsigned)((p.total_segs + 63) / 64)), dim3(64), 0, st, buckets,
                      (uint32_t)p.total_segs, S, T);
-  hipLaunchKernelGGL(reduce_tree_kernel, dim3(p.K + 1, p.W), dim3(p.tree_threads),
+  hipLaunchKernelGGL(reduce_tree_kernel, dim3(p.K + 2, p.W), dim3(p.tree_threads),
                      p.tree_threads * sizeof(PtI), st, (const PtI*)S, (const PtI*)T, p.nseg, p.K,
                      partial);
 }

@@ -143,10 +143,10 @@ Plan make_plan(size_t n, uint32_t c) {
   p.K = p.lb - kSegLog;
   p.total_buckets = (size_t)p.W * p.nb;
   p.total_segs = (size_t)p.W * p.nseg;
-  p.partial_count = (size_t)p.W * (p.K + 1);
+  p.partial_count = (size_t)p.W * (p.K + 2);
   p.max_items = p.total_buckets + ((size_t)p.W * n) / ch + 1;
   uint32_t t = 64;
-  while (t < 1024 && t < std::max(1u, p.nseg / 2)) t <<= 1;
+  while (t < 512 && t < std::max(1u, p.nseg / 2)) t <<= 1;
   p.tree_threads = t;
   return p;
 }
@@ -162,9 +162,9 @@ Plan make_reduce_plan(uint32_t lb, uint32_t W) {
   p.K = lb - kSegLog;
   p.total_buckets = (size_t)p.W * p.nb;
   p.total_segs = (size_t)p.W * p.nseg;
-  p.partial_count = (size_t)p.W * (p.K + 1);
+  p.partial_count = (size_t)p.W * (p.K + 2);
   uint32_t t = 64;
-  while (t < 1024 && t < std::max(1u, p.nseg / 2)) t <<= 1;
+  while (t < 512 && t < std::max(1u, p.nseg / 2)) t <<= 1;
   p.tree_threads = t;
   return p;
 }
@@ -202,15 +202,16 @@ Jacobian normalise(const Jacobian& p) {
   return r;
 }
 
-// Window value  W_w = partial[w][K] + 8 * sum_k 2^k * partial[w][k]  (partial[w][K] = sum T + sum S) and the final Horner
+// Window value  W_w = partial[w][K] + partial[w][K+1] + 8 * sum_k 2^k * partial[w][k]  (sum T, sum S) and the final Horner
 // sum_w 2^(c*w) W_w, fused into ONE pass over bit positions: term partial[w][K] sits at bit c*w,
 // partial[w][k] at bit c*w + 3 + k.  Replaces sum_reduction_final + final_accumulation.rs:19-39.
 Jacobian host_combine(const Jacobian* partial, const Plan& p) {
   const uint32_t top = p.c * p.W;   // exclusive upper bound of bit positions
   std::vector<std::vector<const Jacobian*>> at(top + 1);
   for (uint32_t w = 0; w < p.W; ++w) {
-    const Jacobian* pw = partial + (size_t)w * (p.K + 1);
+    const Jacobian* pw = partial + (size_t)w * (p.K + 2);
     at[p.c * w].push_back(&pw[p.K]);
+    at[p.c * w].push_back(&pw[p.K + 1]);
     for (uint32_t k = 0; k < p.K; ++k) at[p.c * w + kSegLog + k].push_back(&pw[k]);
   }
   Jacobian acc = jac_identity();
@@ -807,7 +808,7 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   Plan one = p;
   one.W = 1;
   for (uint32_t w = 0; w < num_windows; ++w) {
-    const Jacobian r = host_combine(partial.data() + (size_t)w * (p.K + 1), one);
+    const Jacobian r = host_combine(partial.data() + (size_t)w * (p.K + 2), one);
     jac_to_be32(r, res_out + (size_t)w * 24);
   }
   return MSM_AMD_OK;
