@@ -53,7 +53,7 @@ void launch_ark_affine_to_affine(hipStream_t st, const uint8_t* in, uint32_t n, 
 
 // k_accumulate.hip
 void launch_accumulate(hipStream_t st, const Plan& p, const AffI* bases, const SortBuffers& b, PtI* buckets,
-                       PtI* partials);
+                       PtI* partials, bool low_occupancy);
 
 // k_reduce.hip
 int reduce_set_attributes(const char** failed);
