@@ -1,4 +1,4 @@
-// Sort-stage kernels: digit extraction, per-window LDS counting sort, work-item planning.
+// Sort-stage kernels: digit extraction, per-window two-pass LDS counting sort, work-item planning.
 // See device_common.hip.h for the pipeline overview.
 #include "device_common.hip.h"
 #include "launch.h"
@@ -39,48 +39,147 @@ digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage 2a: LDS histogram of one chunk of one window.  grid = (Q, W), block = kSortThreads,
-// dynamic LDS = nb * 4 bytes.
+// Stage 2: per-window sort of the point indices by bucket slot -- a two-pass MSD counting sort.
+//
+// A one-pass scatter (every (chunk, window) workgroup writing 4-byte indices at random positions of the
+// window's 4 MB slice) measured 545 MB of WRITE_SIZE for 71 MB of payload at 2^20: the eight XCD-private L2s
+// evict partially written lines.  So the slot (lb bits) is split into hb coarse + fb fine bits:
+//   pass 1  coarse_hist_kernel / coarse_prefix_kernel / coarse_scatter_kernel
+//           every (chunk q, window w) workgroup moves its points into 2^hb coarse regions of the window.
+//           A workgroup owns one contiguous run per region (positions from returning LDS atomics on 2^hb
+//           region cursors), so its stores extend the same few lines and one L2 assembles them whole.
+//           Payload: index|sign (u32) + fine digit (u16).
+//   pass 2  fine_sort_kernel: one workgroup per (region, window) counting-sorts its ~16 k points over the
+//           2^fb fine slots entirely in LDS (histogram, scan, scatter into an LDS staging buffer) and writes
+//           the region back fully coalesced, together with the bucket sizes.  Regions larger than the staging
+//           buffer (skewed digits) fall back to scattering inside their own slice.
+// The reference sorts 8-byte (bucket, point) pairs of ALL windows on the CPU (sort_buckets.rs:15-34).
+constexpr uint32_t kFineCap = 28672;     // LDS staging entries of pass 2 (112 KB)
+
 __global__ void __launch_bounds__(kSortThreads)
-hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t lb, uint32_t chunk,
-            uint32_t* __restrict__ counts) {
+coarse_hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t fb, uint32_t nhi, uint32_t chunk,
+                   uint32_t* __restrict__ coarse_cnt /* [W][Q][nhi] */) {
   extern __shared__ uint32_t lds_u32[];
-  const uint32_t nb = 1u << lb;
   const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
-  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lds_u32[i] = 0;
+  for (uint32_t i = threadIdx.x; i < nhi; i += blockDim.x) lds_u32[i] = 0;
   __syncthreads();
   const uint32_t lo = q * chunk;
   const uint32_t hi = min(n, lo + chunk);
   const uint16_t* dw = digits + (size_t)w * n;
   for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
-    const uint32_t m = dw[t] & 0x7FFFu;   // magnitude; slot m - 1
-    if (m) atomicAdd(&lds_u32[m - 1], 1u);
+    const uint32_t m = dw[t] & 0x7FFFu;
+    if (m) atomicAdd(&lds_u32[(m - 1) >> fb], 1u);
   }
   __syncthreads();
-  uint32_t* out = counts + ((size_t)w * Q + q) * nb;
-  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) out[i] = lds_u32[i];
+  uint32_t* out = coarse_cnt + ((size_t)w * Q + q) * nhi;
+  for (uint32_t i = threadIdx.x; i < nhi; i += blockDim.x) out[i] = lds_u32[i];
 }
 
-// Stage 2b: per-bucket totals.  One thread per (window, digit): turns counts[w][q][d] into the exclusive
-// prefix over chunks q (position of chunk q's first element inside the bucket) and writes the bucket size.
-__global__ void __launch_bounds__(256)
-chunk_prefix_kernel(uint32_t* __restrict__ counts, uint32_t lb, uint32_t Q, uint32_t W,
-                    uint32_t* __restrict__ bucket_size) {
-  const uint32_t nb = 1u << lb;
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= W * nb) return;
-  const uint32_t w = b >> lb, d = b & (nb - 1);
-  uint32_t* cw = counts + (size_t)w * Q * nb + d;
-  uint32_t run = 0;
-  for (uint32_t q = 0; q < Q; ++q) {
-    const uint32_t cnt = cw[(size_t)q * nb];
-    cw[(size_t)q * nb] = run;
-    run += cnt;
+// grid = W, block = 1024 (>= nhi).  coarse_cnt[w][q][hi] -> first position (inside the window slice) of chunk
+// q's run in region hi; region_start[w][hi] (nhi + 1 entries per window).
+__global__ void __launch_bounds__(1024)
+coarse_prefix_kernel(uint32_t* __restrict__ coarse_cnt, uint32_t Q, uint32_t nhi,
+                     uint32_t* __restrict__ region_start) {
+  __shared__ uint32_t scratch[17];
+  const uint32_t w = blockIdx.x, hi = threadIdx.x;
+  uint32_t* cw = coarse_cnt + (size_t)w * Q * nhi;
+  uint32_t tot = 0;
+  if (hi < nhi)
+    for (uint32_t q = 0; q < Q; ++q) tot += cw[(size_t)q * nhi + hi];
+  uint32_t total;
+  uint32_t start = block_exclusive_scan(tot, scratch, &total);
+  if (hi < nhi) {
+    region_start[(size_t)w * (nhi + 1) + hi] = start;
+    uint32_t run = start;
+    for (uint32_t q = 0; q < Q; ++q) {
+      const uint32_t c = cw[(size_t)q * nhi + hi];
+      cw[(size_t)q * nhi + hi] = run;
+      run += c;
+    }
   }
-  bucket_size[b] = run;
+  if (hi == 0) region_start[(size_t)w * (nhi + 1) + nhi] = total;
 }
 
-// Stage 2c: per-window planning.  grid = W, block = kSortThreads, dynamic LDS = (nb + nb/32 + 33) * 4 bytes.
+// grid = (Q, W), block = 1024, dynamic LDS = nhi * 4 bytes.  The workgroup owns ONE contiguous run per region
+// (coarse_base[w][q][hi] ..): lanes take positions with a returning LDS atomic on the region cursor, so the
+// 2^hb open output lines of a workgroup are written by its own 16 waves only and complete inside one L2.
+__global__ void __launch_bounds__(kSortThreads)
+coarse_scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t hb, uint32_t fb, uint32_t chunk,
+                      const uint32_t* __restrict__ coarse_base /* [W][Q][nhi] */, uint32_t* __restrict__ tmp_idx,
+                      uint16_t* __restrict__ tmp_fine) {
+  extern __shared__ uint32_t lds_u32[];   // [nhi] region cursors
+  const uint32_t nhi = 1u << hb;
+  const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
+  const uint32_t* base = coarse_base + ((size_t)w * Q + q) * nhi;
+  for (uint32_t i = threadIdx.x; i < nhi; i += blockDim.x) lds_u32[i] = base[i];
+  __syncthreads();
+  const uint32_t lo = q * chunk;
+  const uint32_t hi_end = min(n, lo + chunk);
+  const uint16_t* dw = digits + (size_t)w * n;
+  uint32_t* ti = tmp_idx + (size_t)w * n;
+  uint16_t* tf = tmp_fine + (size_t)w * n;
+  const uint32_t fmask = (1u << fb) - 1u;
+  for (uint32_t t = lo + threadIdx.x; t < hi_end; t += blockDim.x) {
+    const uint32_t v = dw[t];
+    const uint32_t m = v & 0x7FFFu;
+    if (m) {
+      const uint32_t slot = m - 1;
+      const uint32_t pos = atomicAdd(&lds_u32[slot >> fb], 1u);
+      ti[pos] = t | ((v >> 15) << 31);   // bit 31: the digit is negative, add -P
+      tf[pos] = (uint16_t)(slot & fmask);
+    }
+  }
+}
+
+// grid = (nhi, W), block = 1024, dynamic LDS = (kFineCap + 2 * nfine + 32) * 4 bytes.
+__global__ void __launch_bounds__(kSortThreads)
+fine_sort_kernel(const uint32_t* __restrict__ tmp_idx, const uint16_t* __restrict__ tmp_fine, uint32_t n,
+                 uint32_t lb, uint32_t fb, const uint32_t* __restrict__ region_start,
+                 uint32_t* __restrict__ sorted, uint32_t* __restrict__ bucket_size) {
+  extern __shared__ uint32_t lds_u32[];
+  const uint32_t nfine = 1u << fb;
+  const uint32_t nhi = gridDim.x;
+  const uint32_t hi = blockIdx.x, w = blockIdx.y;
+  uint32_t* bins = lds_u32;                 // [nfine] counts, then cursors
+  uint32_t* scratch = lds_u32 + nfine;      // 17 words (block scan)
+  uint32_t* staging = lds_u32 + nfine + 32; // [kFineCap]
+  const uint32_t rs = region_start[(size_t)w * (nhi + 1) + hi];
+  const uint32_t re = region_start[(size_t)w * (nhi + 1) + hi + 1];
+  const uint32_t size = re - rs;
+  const uint32_t* ti = tmp_idx + (size_t)w * n + rs;
+  const uint16_t* tf = tmp_fine + (size_t)w * n + rs;
+  uint32_t* out = sorted + (size_t)w * n + rs;
+  for (uint32_t i = threadIdx.x; i < nfine; i += blockDim.x) bins[i] = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) atomicAdd(&bins[tf[i]], 1u);
+  __syncthreads();
+  // exclusive scan of the fine histogram (nfine <= 1024: one bin per thread)
+  const uint32_t cnt = (threadIdx.x < nfine) ? bins[threadIdx.x] : 0u;
+  uint32_t total;
+  const uint32_t start = block_exclusive_scan(cnt, scratch, &total);
+  if (threadIdx.x < nfine) {
+    bins[threadIdx.x] = start;
+    const uint32_t slot = (hi << fb) | threadIdx.x;
+    if (slot < (1u << lb)) bucket_size[((size_t)w << lb) + slot] = cnt;
+  }
+  __syncthreads();
+  if (size <= kFineCap) {
+    for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) {
+      const uint32_t pos = atomicAdd(&bins[tf[i]], 1u);
+      staging[pos] = ti[i];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) out[i] = staging[i];
+  } else {
+    for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) {
+      const uint32_t pos = atomicAdd(&bins[tf[i]], 1u);
+      out[pos] = ti[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 2 (end): per-window planning.  grid = W, block = kSortThreads, dynamic LDS = (nb + nb/32 + 33) * 4 bytes.
 // Two exclusive scans over the window's buckets (one LDS array, used twice):
 //   bucket_start[w][d] = offset of bucket d inside the window's slice of `sorted`
 //   item_start[w][d]   = first work-item id of bucket d inside the window, where a bucket of s points
@@ -129,34 +228,6 @@ plan_kernel(const uint32_t* __restrict__ bucket_size, uint32_t lb, uint32_t CH,
   const uint32_t total_items = window_scan_lds(tot, scratch, nb);
   for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) item_start[(size_t)w * nb + d] = tot[d + (d >> 5)];
   if (threadIdx.x == 0) win_items[w] = total_items;
-}
-
-// Stage 2d: scatter point indices to their bucket slots.  grid = (Q, W), dynamic LDS = nb * 4 bytes.
-// Order inside a bucket is unspecified (LDS atomic arrival order), exactly as the reference allows
-// (sort_buckets.rs:111-125 checks only multiset + non-decreasing keys).
-__global__ void __launch_bounds__(kSortThreads)
-scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t lb, uint32_t chunk,
-               const uint32_t* __restrict__ chunk_prefix, const uint32_t* __restrict__ bucket_start,
-               uint32_t* __restrict__ sorted) {
-  extern __shared__ uint32_t lds_u32[];
-  const uint32_t nb = 1u << lb;
-  const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
-  const uint32_t* rel = chunk_prefix + ((size_t)w * Q + q) * nb;
-  const uint32_t* bs = bucket_start + (size_t)w * nb;
-  for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lds_u32[i] = bs[i] + rel[i];
-  __syncthreads();
-  const uint32_t lo = q * chunk;
-  const uint32_t hi = min(n, lo + chunk);
-  const uint16_t* dw = digits + (size_t)w * n;
-  uint32_t* sw = sorted + (size_t)w * n;
-  for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
-    const uint32_t v = dw[t];
-    const uint32_t m = v & 0x7FFFu;
-    if (m) {
-      const uint32_t pos = atomicAdd(&lds_u32[m - 1], 1u);
-      sw[pos] = t | ((v >> 15) << 31);   // bit 31: the digit is negative, add -P
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -290,14 +361,13 @@ be32_to_le_kernel(const uint32_t* __restrict__ in, size_t words, uint32_t* __res
 
 
 // ------------------------------------------------------------------------------------------------
-static size_t lds_hist_bytes(uint32_t lb) { return (size_t)(1u << lb) * 4; }
 static size_t lds_plan_bytes(uint32_t lb) { return ((size_t)(1u << lb) + ((1u << lb) >> 5) + 33) * 4; }
 
 int sort_set_attributes(const char** failed) {
   const int max_lds = 160 * 1024;
-  struct { const void* fn; const char* name; } ks[] = {{(const void*)hist_kernel, "hist_kernel"},
-                                                        {(const void*)plan_kernel, "plan_kernel"},
-                                                        {(const void*)scatter_kernel, "scatter_kernel"}};
+  struct { const void* fn; const char* name; } ks[] = {{(const void*)plan_kernel, "plan_kernel"},
+                                                        {(const void*)coarse_scatter_kernel, "coarse_scatter_kernel"},
+                                                        {(const void*)fine_sort_kernel, "fine_sort_kernel"}};
   for (auto& k : ks) {
     if (hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess) {
       (void)hipGetLastError();
@@ -314,15 +384,18 @@ void launch_digits(hipStream_t st, const Plan& p, const u256* scalars, int scala
 }
 
 void launch_sort(hipStream_t st, const Plan& p, const SortBuffers& b) {
-  hipLaunchKernelGGL(hist_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.lb), st,
-                     (const uint16_t*)b.digits, p.n, p.lb, p.chunk, b.counts);
-  hipLaunchKernelGGL(chunk_prefix_kernel, dim3((unsigned)((p.total_buckets + 255) / 256)), dim3(256), 0, st,
-                     b.counts, p.lb, p.Q, p.W, b.bucket_size);
+  const uint32_t nhi = 1u << p.hb, nfine = 1u << p.fb;
+  hipLaunchKernelGGL(coarse_hist_kernel, dim3(p.Q, p.W), dim3(kSortThreads), nhi * 4, st,
+                     (const uint16_t*)b.digits, p.n, p.fb, nhi, p.chunk, b.coarse_cnt);
+  hipLaunchKernelGGL(coarse_prefix_kernel, dim3(p.W), dim3(1024), 0, st, b.coarse_cnt, p.Q, nhi, b.region_start);
+  hipLaunchKernelGGL(coarse_scatter_kernel, dim3(p.Q, p.W), dim3(kSortThreads), nhi * 4, st,
+                     (const uint16_t*)b.digits, p.n, p.hb, p.fb, p.chunk, (const uint32_t*)b.coarse_cnt, b.tmp_idx,
+                     b.tmp_fine);
+  hipLaunchKernelGGL(fine_sort_kernel, dim3(nhi, p.W), dim3(kSortThreads), (kFineCap + nfine + 32) * 4, st,
+                     (const uint32_t*)b.tmp_idx, (const uint16_t*)b.tmp_fine, p.n, p.lb, p.fb,
+                     (const uint32_t*)b.region_start, b.sorted, b.bucket_size);
   hipLaunchKernelGGL(plan_kernel, dim3(p.W), dim3(kSortThreads), lds_plan_bytes(p.lb), st,
                      (const uint32_t*)b.bucket_size, p.lb, p.CH, b.bucket_start, b.item_start, b.win_items);
-  hipLaunchKernelGGL(scatter_kernel, dim3(p.Q, p.W), dim3(kSortThreads), lds_hist_bytes(p.lb), st,
-                     (const uint16_t*)b.digits, p.n, p.lb, p.chunk, (const uint32_t*)b.counts,
-                     (const uint32_t*)b.bucket_start, b.sorted);
   (void)hipMemsetAsync(b.size_bins, 0, (p.CH + 1) * sizeof(uint32_t), st);
   const unsigned gb = (unsigned)((p.total_buckets + kSizeThreads - 1) / kSizeThreads);
   hipLaunchKernelGGL(size_hist_kernel, dim3(gb), dim3(kSizeThreads), (p.CH + 1) * 4, st,

@@ -17,6 +17,7 @@ struct Plan {
   uint32_t n, c, W;           // points, window bits, windows (signed digits: W = floor(254/c) + 1)
   uint32_t lb, nb;            // bucket slots per window nb = 2^lb = max(2^(c-1), 8); slot i holds |digit| = i + 1
   uint32_t Q, chunk;          // sort: chunks per window, points per chunk
+  uint32_t hb, fb;            // sort: coarse / fine bits of the slot (hb + fb = lb)
   uint32_t CH;                // accumulate: max points per work item (bucket chunk)
   uint32_t nseg, K;           // reduce: segments per window, bits of segment index (lb - 3)
   uint32_t tree_threads;
@@ -32,7 +33,10 @@ struct PlanCounters {
 
 struct SortBuffers {
   uint16_t* digits;           // [W][n]
-  uint32_t* counts;           // [W][Q][nb]
+  uint32_t* coarse_cnt;       // [W][Q][2^hb]  per-chunk region counts, then write positions
+  uint32_t* region_start;     // [W][2^hb + 1]
+  uint32_t* tmp_idx;          // [W][n]        pass-1 output: index | sign << 31, grouped by coarse region
+  uint16_t* tmp_fine;         // [W][n]        pass-1 output: fine digit
   uint32_t* bucket_size;      // [W][nb]
   uint32_t* bucket_start;     // [W][nb]   offset inside the window's slice of `sorted`
   uint32_t* item_start;       // [W][nb]   first item id of the bucket inside its window

@@ -50,7 +50,7 @@ struct InstanceSlot {
 // reduction, planning kernels) overlaps the throughput-bound bucket accumulation of the next one.
 struct Workspace {
   hipStream_t stream = nullptr;
-  DeviceBuf digits, counts, bsize, bstart, istart, win_items, size_bins, sorted, order, multi_list, counters,
+  DeviceBuf digits, coarse_cnt, region_start, tmp_idx, tmp_fine, bsize, bstart, istart, win_items, size_bins, sorted, order, multi_list, counters,
       bases29, buckets, item_partials, S, T, partial, conv_scalars, conv_points, conv_tmp;
 };
 
@@ -122,12 +122,21 @@ Plan make_plan(size_t n, uint32_t c) {
   p.W = kModulusBits / c + 1;         // signed digits: the top window absorbs the last carry (= ceil(255 / c))
   p.lb = std::max(c - 1, (uint32_t)kSegLog);
   p.nb = 1u << p.lb;                  // slot i <-> digit magnitude i + 1 (c = 3 is padded to 8 slots)
-  // one 1024-thread workgroup (whole-window LDS histogram) per (chunk, window): aim at ~1 per CU
-  uint32_t Q = std::max(1u, 256u / p.W);
+  // sort pass 1: one 1024-thread workgroup per (chunk, window), about two per CU
+  uint32_t Q = std::max(1u, 512u / p.W);
   const uint32_t max_q = (uint32_t)((n + 4095) / 4096);
   Q = std::max(1u, std::min(Q, max_q));
   p.Q = Q;
-  p.chunk = (uint32_t)((n + Q - 1) / Q);
+  p.chunk = (uint32_t)((((n + Q - 1) / Q) + 63) & ~(size_t)63);
+  // coarse regions of ~16 k points so that pass 2 sorts a region inside LDS; at least 2 fine bits
+  uint32_t hb = 0;
+  while (hb + 2 < p.lb && hb < 10 && (n >> hb) > 16384) ++hb;
+  p.hb = hb;
+  p.fb = p.lb - hb;
+  if (p.fb > 10) {   // the fine histogram is scanned with one bin per thread (<= 1024 bins)
+    p.fb = 10;
+    p.hb = p.lb - 10;
+  }
   // accumulate work items: at most CH points each.  The accumulate kernel wants >= ~400 k items (two full
   // rounds of 3 waves/SIMD on 1024 SIMDs) so that the chip stays full until the end; buckets longer than CH
   // are cut into several items whose partial sums the combine kernels add up (one extra addition per cut).
@@ -337,7 +346,10 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   int rc;
   if ((rc = slot_prepare(ctx, slot, p.partial_count))) return rc;
   if ((rc = ensure(ctx, w.digits, (size_t)p.W * n * sizeof(uint16_t)))) return rc;
-  if ((rc = ensure(ctx, w.counts, (size_t)p.W * p.Q * p.nb * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.coarse_cnt, (size_t)p.W * p.Q * (1u << p.hb) * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.region_start, (size_t)p.W * ((1u << p.hb) + 1) * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.tmp_idx, (size_t)p.W * n * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.tmp_fine, (size_t)p.W * n * sizeof(uint16_t)))) return rc;
   if ((rc = ensure(ctx, w.bsize, p.total_buckets * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.bstart, p.total_buckets * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.istart, p.total_buckets * sizeof(uint32_t)))) return rc;
@@ -352,7 +364,10 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   if ((rc = ensure(ctx, w.item_partials, p.max_items * sizeof(PtI)))) return rc;
   SortBuffers sb{};
   sb.digits = (uint16_t*)w.digits.p;
-  sb.counts = (uint32_t*)w.counts.p;
+  sb.coarse_cnt = (uint32_t*)w.coarse_cnt.p;
+  sb.region_start = (uint32_t*)w.region_start.p;
+  sb.tmp_idx = (uint32_t*)w.tmp_idx.p;
+  sb.tmp_fine = (uint16_t*)w.tmp_fine.p;
   sb.bucket_size = (uint32_t*)w.bsize.p;
   sb.bucket_start = (uint32_t*)w.bstart.p;
   sb.item_start = (uint32_t*)w.istart.p;
@@ -585,7 +600,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   for (int k = 0; k < ctx->nstreams; ++k) (void)hipStreamSynchronize(ctx->ws[k].stream);
   for (int k = 0; k < kMaxStreams; ++k) {
     Workspace& w = ctx->ws[k];
-    DeviceBuf* bufs[] = {&w.digits, &w.counts, &w.bsize, &w.bstart, &w.istart, &w.win_items, &w.size_bins, &w.sorted,
+    DeviceBuf* bufs[] = {&w.digits, &w.coarse_cnt, &w.region_start, &w.tmp_idx, &w.tmp_fine, &w.bsize, &w.bstart, &w.istart, &w.win_items, &w.size_bins, &w.sorted,
                          &w.order, &w.multi_list, &w.counters, &w.bases29, &w.buckets, &w.item_partials, &w.S, &w.T,
                          &w.partial, &w.conv_scalars, &w.conv_points, &w.conv_tmp};
     for (DeviceBuf* b : bufs)
