@@ -240,7 +240,7 @@ plan_kernel(const uint32_t* __restrict__ bucket_size, uint32_t lb, uint32_t CH,
 //                        scan of win_items (-> window base of item ids), total item count
 //   size_scatter_kernel  every bucket reserves its positions: one LDS-aggregated global atomic per
 //                        (workgroup, size class), LDS atomics inside the workgroup
-constexpr int kSizeThreads = 256;
+constexpr int kSizeThreads = 1024;
 
 __device__ __forceinline__ void bucket_items(uint32_t s, uint32_t CH, uint32_t* nfull, uint32_t* last) {
   // s points -> nfull items of CH points + (last ? one item of `last` points : none)

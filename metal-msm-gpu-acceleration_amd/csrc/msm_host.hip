@@ -45,22 +45,28 @@ struct InstanceSlot {
 
 }  // namespace
 
-// Device buffers of one in-flight MSM.  A ctx owns kStreams of these, each with its own HIP stream:
-// instance i of a batch runs on workspace i % nstreams, so the latency-bound tail of one instance (window
-// reduction, planning kernels) overlaps the throughput-bound bucket accumulation of the next one.
+// Device buffers of one in-flight MSM.  A ctx owns two of them and alternates: the window reduction of
+// instance i runs on a side stream while the main stream already sorts (and then accumulates) instance i+1 in
+// the other workspace.  The reduction is latency-bound (about 25 dependent point additions on a few hundred
+// workgroups) and so is the sort front-end; running them side by side hides the shorter of the two.  (Running
+// whole instances on parallel streams was tried and gained little: a resident accumulate grid keeps the
+// 1024-thread sort workgroups of the other stream from being placed at all.)
 struct Workspace {
-  hipStream_t stream = nullptr;
-  DeviceBuf digits, coarse_cnt, region_start, tmp_idx, tmp_fine, bsize, bstart, istart, win_items, size_bins, sorted, order, multi_list, counters,
-      bases29, buckets, item_partials, S, T, partial, conv_scalars, conv_points, conv_tmp;
+  DeviceBuf digits, coarse_cnt, region_start, tmp_idx, tmp_fine, bsize, bstart, istart, win_items, size_bins, sorted,
+      order, multi_list, counters, bases29, buckets, item_partials, S, T, partial, conv_scalars, conv_points, conv_tmp;
+  hipEvent_t acc_done = nullptr;      // main stream: buckets of this workspace are complete
+  hipEvent_t reduce_done = nullptr;   // side stream: buckets / partial of this workspace are free again
+  bool reduce_pending = false;
 };
 
-constexpr int kMaxStreams = 4;
+constexpr int kWorkspaces = 2;
 
 struct msm_amd_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;      // == ws[0].stream; used by the stage / helper entry points
-  int nstreams = 1;   // MSM_AMD_STREAMS=2..4 overlaps instances; measured +6 % at best on MI355X
-  Workspace ws[kMaxStreams];
+  hipStream_t stream = nullptr;          // main stream: conversion, digits, sort, accumulate; stage entry points
+  hipStream_t reduce_stream = nullptr;   // side stream: window reduction + copy of the partial points
+  bool overlap_reduce = true;            // MSM_AMD_OVERLAP_REDUCE=0 puts everything on the main stream
+  Workspace ws[kWorkspaces];
   std::mutex mu;
   std::string last_error;
   uint32_t forced_window = 0;
@@ -257,7 +263,7 @@ int slot_prepare(msm_amd_ctx* ctx, InstanceSlot& s, size_t partial_count) {
 int convert_inputs(msm_amd_ctx* ctx, Workspace& w, int scalar_layout, int point_layout, const void* d_scalars,
                    const void* d_points, size_t n, const u256** scalars_native, int* scalars_mont,
                    const Affine** points_native) {
-  hipStream_t st = w.stream;
+  hipStream_t st = ctx->stream;
   switch (scalar_layout) {
     case MSM_AMD_SCALAR_MONT_LE:
       *scalars_native = (const u256*)d_scalars;
@@ -325,8 +331,7 @@ size_t point_bytes(int layout) {
 }
 
 // Window reduction of a production-layout bucket matrix: buckets [W][nb] -> partial [W][K+1] on device.
-int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, const Plan& p, const PtI* buckets) {
-  hipStream_t st = w.stream;
+int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, hipStream_t st, const Plan& p, const PtI* buckets) {
   int rc;
   if ((rc = ensure(ctx, w.S, p.total_segs * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.T, p.total_segs * sizeof(PtI)))) return rc;
@@ -339,7 +344,7 @@ int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, const Plan& p, const PtI* buc
 // Enqueue one whole MSM on the ctx stream; results land in slot.h_partial after slot.ev[EV_REDUCE].
 int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_layout, int point_layout, const void* d_scalars,
                 const void* d_points, size_t n, Plan* plan_out) {
-  hipStream_t st = w.stream;
+  hipStream_t st = ctx->stream;
   const uint32_t c = ctx->forced_window ? ctx->forced_window : auto_window(n);
   const Plan p = make_plan(n, c);
   *plan_out = p;
@@ -378,6 +383,10 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   sb.multi_list = (uint32_t*)w.multi_list.p;
   sb.counters = (PlanCounters*)w.counters.p;
 
+  if (w.reduce_pending) {   // the previous user of this workspace may still be reducing its buckets
+    HIP_TRY(ctx, hipStreamWaitEvent(st, w.reduce_done, 0));
+    w.reduce_pending = false;
+  }
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_START], st));
   const u256* sc = nullptr;
   const Affine* pts = nullptr;
@@ -392,14 +401,23 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   launch_sort(st, p, sb);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_SORT], st));
 
-  launch_accumulate(st, p, (const AffI*)w.bases29.p, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p,
-                    ctx->nstreams > 1);
+  launch_accumulate(st, p, (const AffI*)w.bases29.p, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p, false);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
 
-  if ((rc = enqueue_reduce(ctx, w, p, (const PtI*)w.buckets.p))) return rc;
+  // window reduction + result copy: on the side stream, so that the main stream can start the next instance
+  hipStream_t rs = ctx->overlap_reduce ? ctx->reduce_stream : st;
+  if (ctx->overlap_reduce) {
+    HIP_TRY(ctx, hipEventRecord(w.acc_done, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(rs, w.acc_done, 0));
+  }
+  if ((rc = enqueue_reduce(ctx, w, rs, p, (const PtI*)w.buckets.p))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial, w.partial.p, p.partial_count * sizeof(Jacobian),
-                              hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_REDUCE], st));
+                              hipMemcpyDeviceToHost, rs));
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_REDUCE], rs));
+  if (ctx->overlap_reduce) {
+    HIP_TRY(ctx, hipEventRecord(w.reduce_done, rs));
+    w.reduce_pending = true;
+  }
   HIP_TRY(ctx, hipGetLastError());
   return MSM_AMD_OK;
 }
@@ -446,10 +464,11 @@ int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size
   std::vector<Plan> plans(n_inst);
   ctx->timings = msm_amd_timings{};
   for (size_t i = 0; i < n_inst; ++i) {
-    Workspace& w = ctx->ws[i % (size_t)ctx->nstreams];
+    Workspace& w = ctx->ws[i % (size_t)kWorkspaces];
     int rc = enqueue_msm(ctx, w, ctx->slots[i], scalar_layout, point_layout, d_scalars[i], d_points[i], n[i], &plans[i]);
     if (rc) {
-      for (int k = 0; k < ctx->nstreams; ++k) (void)hipStreamSynchronize(ctx->ws[k].stream);
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipStreamSynchronize(ctx->reduce_stream);
       return rc;
     }
   }
@@ -463,7 +482,9 @@ int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size
     std::memcpy((uint8_t*)out_host + i * 96, &res, 96);
     accumulate_timings(ctx, s, plans[i], final_ms, n_inst);
   }
-  for (int k = 0; k < ctx->nstreams; ++k) HIP_TRY(ctx, hipStreamSynchronize(ctx->ws[k].stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->reduce_stream));
+  for (int k = 0; k < kWorkspaces; ++k) ctx->ws[k].reduce_pending = false;
   return MSM_AMD_OK;
 }
 
@@ -548,22 +569,22 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   }
   msm_amd_ctx* ctx = new msm_amd_ctx();
   ctx->device = device;
-  if (const char* e = std::getenv("MSM_AMD_STREAMS")) {
-    const int k = std::atoi(e);
-    if (k >= 1 && k <= kMaxStreams) ctx->nstreams = k;
+  if (const char* e = std::getenv("MSM_AMD_OVERLAP_REDUCE")) ctx->overlap_reduce = std::atoi(e) != 0;
+  bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&ctx->reduce_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int k = 0; ok && k < kWorkspaces; ++k)
+    ok = hipEventCreateWithFlags(&ctx->ws[k].acc_done, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ctx->ws[k].reduce_done, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    delete ctx;
+    return MSM_AMD_PIPELINE_ERROR;
   }
-  for (int k = 0; k < ctx->nstreams; ++k) {
-    if (hipStreamCreateWithFlags(&ctx->ws[k].stream, hipStreamNonBlocking) != hipSuccess) {
-      for (int j = 0; j < k; ++j) (void)hipStreamDestroy(ctx->ws[j].stream);
-      delete ctx;
-      return MSM_AMD_PIPELINE_ERROR;
-    }
-  }
-  ctx->stream = ctx->ws[0].stream;
   int rc = set_kernel_attributes(ctx);
   if (rc) {
     std::fprintf(stderr, "msm_amd: %s\n", ctx->last_error.c_str());
-    for (int k = 0; k < ctx->nstreams; ++k) (void)hipStreamDestroy(ctx->ws[k].stream);
+    (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->reduce_stream);
     delete ctx;
     return rc;
   }
@@ -597,14 +618,17 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (ctx == g_global_ctx) g_global_ctx = nullptr;
   }
   (void)hipSetDevice(ctx->device);
-  for (int k = 0; k < ctx->nstreams; ++k) (void)hipStreamSynchronize(ctx->ws[k].stream);
-  for (int k = 0; k < kMaxStreams; ++k) {
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->reduce_stream);
+  for (int k = 0; k < kWorkspaces; ++k) {
     Workspace& w = ctx->ws[k];
     DeviceBuf* bufs[] = {&w.digits, &w.coarse_cnt, &w.region_start, &w.tmp_idx, &w.tmp_fine, &w.bsize, &w.bstart, &w.istart, &w.win_items, &w.size_bins, &w.sorted,
                          &w.order, &w.multi_list, &w.counters, &w.bases29, &w.buckets, &w.item_partials, &w.S, &w.T,
                          &w.partial, &w.conv_scalars, &w.conv_points, &w.conv_tmp};
     for (DeviceBuf* b : bufs)
       if (b->p) (void)hipFree(b->p);
+    if (w.acc_done) (void)hipEventDestroy(w.acc_done);
+    if (w.reduce_done) (void)hipEventDestroy(w.reduce_done);
   }
   DeviceBuf* sbufs[] = {&ctx->scratch_a, &ctx->scratch_b, &ctx->scratch_c};
   for (DeviceBuf* b : sbufs)
@@ -614,7 +638,8 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
       for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(s.ev[i]);
     if (s.h_partial) (void)hipHostFree(s.h_partial);
   }
-  for (int k = 0; k < ctx->nstreams; ++k) (void)hipStreamDestroy(ctx->ws[k].stream);
+  (void)hipStreamDestroy(ctx->stream);
+  (void)hipStreamDestroy(ctx->reduce_stream);
   delete ctx;
 }
 
@@ -703,7 +728,8 @@ int msm_amd_synchronize(msm_amd_ctx* ctx) {
   if (!ctx) return MSM_AMD_INPUT_ERROR;
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  for (int k = 0; k < ctx->nstreams; ++k) HIP_TRY(ctx, hipStreamSynchronize(ctx->ws[k].stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->reduce_stream));
   return MSM_AMD_OK;
 }
 
@@ -815,7 +841,7 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   const size_t words = (size_t)buckets_size * num_windows * 3;
   launch_be32_to_le(st, (const uint32_t*)ctx->scratch_a.p, words, (uint32_t*)ctx->scratch_b.p);
   launch_pad_buckets(st, (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.lb, (PtI*)ctx->ws[0].buckets.p);
-  if ((rc = enqueue_reduce(ctx, ctx->ws[0], p, (const PtI*)ctx->ws[0].buckets.p))) return rc;
+  if ((rc = enqueue_reduce(ctx, ctx->ws[0], st, p, (const PtI*)ctx->ws[0].buckets.p))) return rc;
   std::vector<Jacobian> partial(p.partial_count);
   HIP_TRY(ctx, hipMemcpyAsync(partial.data(), ctx->ws[0].partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, st));
