@@ -252,9 +252,53 @@ struct Field {
     return r;
   }
 
-  // Montgomery product a*b*R^-1 mod p, product scanning with interleaved reduction (FIPS).
-  // Replaces FpBN254::mul (fp_bn254.h.metal:237-290, operand-scanning CIOS on MS-first limbs).
+  // Montgomery product a*b*R^-1 mod p.
+  // Device: product scanning with interleaved reduction (FIPS) on 32-bit limbs; replaces FpBN254::mul
+  // (fp_bn254.h.metal:237-290, operand-scanning CIOS on MS-first limbs).
+  // Host (final Horner pass, input conversion checks): the same value computed with 4 x 64-bit limbs and
+  // unsigned __int128 (CIOS), about 3x faster on a CPU core; u256 is little-endian so the limbs alias.
   MSM_HD static u256 mul(const u256& a, const u256& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned __int128 u128;
+    uint64_t x[4], y[4], pm[4];
+    for (int i = 0; i < 4; ++i) {
+      x[i] = ((uint64_t)a.v[2 * i + 1] << 32) | a.v[2 * i];
+      y[i] = ((uint64_t)b.v[2 * i + 1] << 32) | b.v[2 * i];
+      pm[i] = ((uint64_t)F::mod(2 * i + 1) << 32) | F::mod(2 * i);
+    }
+    // -p^-1 mod 2^64 from the 32-bit constant by one Newton step: inv64 = inv32 * (2 + p0 * inv32)
+    // (with inv = -p^-1: x' = x * (2 + p * x) doubles the number of correct bits)
+    const uint64_t inv32 = F::INV;
+    const uint64_t inv64 = inv32 * (2 + pm[0] * inv32);
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+      u128 c = 0;
+      for (int j = 0; j < 4; ++j) {
+        c += (u128)x[j] * y[i] + t[j];
+        t[j] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[4];
+      t[4] = (uint64_t)c;
+      t[5] = (uint64_t)(c >> 64);
+      const uint64_t m = t[0] * inv64;
+      c = ((u128)m * pm[0] + t[0]) >> 64;
+      for (int j = 1; j < 4; ++j) {
+        c += (u128)m * pm[j] + t[j];
+        t[j - 1] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[4];
+      t[3] = (uint64_t)c;
+      t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    u256 r;
+    for (int i = 0; i < 4; ++i) {
+      r.v[2 * i] = (uint32_t)t[i];
+      r.v[2 * i + 1] = (uint32_t)(t[i] >> 32);
+    }
+    return reduce_once(r);   // t < 2p fits 256 bits (t[4] == 0)
+#else
     uint64_t lo = 0;
     uint32_t hi = 0;
     uint32_t m[8];
@@ -276,6 +320,7 @@ struct Field {
     }
     r.v[7] = (uint32_t)lo;
     return reduce_once(r);
+#endif
   }
 
   MSM_HD static u256 sqr(const u256& a) { return mul(a, a); }
