@@ -67,7 +67,9 @@ typedef struct msm_amd_timings {
   uint32_t n;
   uint32_t window_size;
   uint32_t num_windows;
-  uint32_t reserved;
+  uint32_t reserved;            /* number of instances the averages were taken over */
+  float accumulate_kernel_ms;   /* accumulate_kernel alone (events directly around its launch) */
+  float reserved2[3];
 } msm_amd_timings;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

@@ -44,7 +44,8 @@ EXPORTS = [
 class Timings(ctypes.Structure):
     _fields_ = [("convert_ms", c_float), ("digits_ms", c_float), ("sort_ms", c_float), ("accumulate_ms", c_float),
                 ("reduce_ms", c_float), ("final_ms", c_float), ("total_gpu_ms", c_float), ("n", c_uint32),
-                ("window_size", c_uint32), ("num_windows", c_uint32), ("reserved", c_uint32)]
+                ("window_size", c_uint32), ("num_windows", c_uint32), ("reserved", c_uint32),
+                ("accumulate_kernel_ms", c_float), ("reserved2", c_float * 3)]
 
 
 class MsmError(RuntimeError):

@@ -1,6 +1,8 @@
 // BN254 G1 group law on the 29-bit-limb internal representation (bn254_fq29.hip.h) -- the arithmetic of
 // the hot kernels (accumulate, combine, window reduction).  Points in HBM:
-//   AffI  80 bytes: x, y (9 limbs each) + 2 pad words -> five 16-byte loads per gathered base
+//   AffPacked 64 bytes: canonical x, y of the internal Montgomery domain, bit-packed -> four 16-byte loads per
+//        gathered base, never straddling a 64-byte boundary (80-byte records measured 2.3x slower to gather:
+//        tools/microbench/gather_calib.hip); unpacked to 2 x 9 limbs (AffI) in registers
 //   PtI  144 bytes: X, Y, ZZ, ZZZ (9 limbs each), extended Jacobian ("XYZZ": x = X/ZZ, y = Y/ZZZ,
 //        ZZ^3 = ZZZ^2); ZZ limbs all zero = identity
 // Formulas (EFD, short Weierstrass a = 0, XYZZ): mixed addition madd-2008-s (8M + 2S), addition add-2008-s
@@ -21,14 +23,16 @@
 
 namespace msm_amd {
 
-struct AffI {
+struct AffI {   // register form of a base point
   fe29 x, y;
-  uint32_t pad[2];
+};
+struct AffPacked {   // memory form: canonical x, y in the internal Montgomery domain, 2 x 32 bytes
+  u256 x, y;
 };
 struct PtI {
   fe29 x, y, zz, zzz;
 };
-static_assert(sizeof(AffI) == 80, "AffI must be 80 bytes");
+static_assert(sizeof(AffPacked) == 64, "AffPacked must be 64 bytes");
 static_assert(sizeof(PtI) == 144, "PtI must be 144 bytes");
 
 MSM_HD bool affi_is_identity(const AffI& p) {
@@ -66,7 +70,20 @@ MSM_HD AffI affi_from_ext(const Affine& p) {
     r.x = Fq29::from_ext(p.x);
     r.y = Fq29::from_ext(p.y);
   }
-  r.pad[0] = r.pad[1] = 0;
+  return r;
+}
+
+MSM_HD AffPacked affi_pack(const AffI& p) {   // p from affi_from_ext (multiplication outputs or exact zeros)
+  AffPacked r;
+  r.x = Fq29::pack_canonical(p.x);
+  r.y = Fq29::pack_canonical(p.y);
+  return r;
+}
+
+MSM_HD AffI affi_unpack(const AffPacked& p) {
+  AffI r;
+  r.x = Fq29::unpack256(p.x);
+  r.y = Fq29::unpack256(p.y);
   return r;
 }
 

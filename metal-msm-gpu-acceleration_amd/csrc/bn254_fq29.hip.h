@@ -161,8 +161,8 @@ struct Fq29 {
     return reduce_columns(A);
   }
 
-  // External (8 x u32 little-endian, Montgomery R = 2^256, canonical) -> internal.
-  MSM_HD static fe29 from_ext(const u256& x) {
+  // 256-bit little-endian integer -> 9 x 29-bit limbs (pure bit slicing, value unchanged).
+  MSM_HD static fe29 unpack256(const u256& x) {
     fe29 t;
     MSM_UNROLL for (int i = 0; i < 9; ++i) {
       const int bit = 29 * i;
@@ -171,9 +171,28 @@ struct Fq29 {
       if (s > 3 && w + 1 < 8) v |= x.v[w + 1] << (32 - s);
       t.l[i] = (i < 8) ? (v & MASK) : v;
     }
+    return t;
+  }
+
+  // Canonical limbs (each < 2^29, value < 2^256) -> 256-bit little-endian integer.
+  MSM_HD static u256 pack256(const fe29& t) {
+    u256 r;
+    MSM_UNROLL for (int w = 0; w < 8; ++w) {
+      const int bit = 32 * w;
+      const int i = bit / 29, s = bit % 29;
+      uint32_t v = t.l[i] >> s;
+      if (i + 1 < 9) v |= t.l[i + 1] << (29 - s);
+      if (29 - s + 29 < 32 && i + 2 < 9) v |= t.l[i + 2] << (58 - s);
+      r.v[w] = v;
+    }
+    return r;
+  }
+
+  // External (8 x u32 little-endian, Montgomery R = 2^256, canonical) -> internal.
+  MSM_HD static fe29 from_ext(const u256& x) {
     fe29 c;
     MSM_UNROLL for (int i = 0; i < 9; ++i) c.l[i] = cin_c(i);
-    return mul(t, c);
+    return mul(unpack256(x), c);
   }
 
   // Exact carry propagation + at most `rounds` conditional subtractions of p; input limbs arbitrary u32
@@ -205,18 +224,12 @@ struct Fq29 {
   MSM_HD static u256 to_ext(const fe29& a) {
     fe29 d;
     MSM_UNROLL for (int i = 0; i < 9; ++i) d.l[i] = dout_c(i);
-    const fe29 t = canonical(mul(a, d), 1);   // mul output < 1.3 p
-    u256 r;
-    MSM_UNROLL for (int w = 0; w < 8; ++w) {
-      const int bit = 32 * w;
-      const int i = bit / 29, s = bit % 29;
-      uint32_t v = t.l[i] >> s;
-      if (i + 1 < 9) v |= t.l[i + 1] << (29 - s);
-      if (29 - s + 29 < 32 && i + 2 < 9) v |= t.l[i + 2] << (58 - s);
-      r.v[w] = v;
-    }
-    return r;
+    return pack256(canonical(mul(a, d), 1));   // mul output < 1.3 p
   }
+
+  // Internal (a multiplication result: exact limbs, value < 2 p) -> canonical value packed into 32 bytes, still
+  // in the internal Montgomery domain; unpack256 restores limbs.  Storage format of the gathered bases.
+  MSM_HD static u256 pack_canonical(const fe29& a) { return pack256(canonical(a, 1)); }
 
   // Cheap necessary condition for a == 0 (mod p) given value(a) < bound * p: if a = j*p then the low 29
   // bits satisfy j = a0 * p^-1 mod 2^29 < bound.  Low limb bits are exact even for lazy limbs.

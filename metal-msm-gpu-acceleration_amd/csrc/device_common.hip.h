@@ -8,7 +8,7 @@
 //   chunk_prefix_kernel  counts -> bucket_size[W][nb], counts := exclusive prefix over chunks
 //   scan_kernel          bucket_size -> bucket_start[W][nb]  (per-window exclusive scan in LDS)
 //   scatter_kernel       digits + cursors -> sorted[W][n]  (point indices grouped by digit)
-//   convert_bases_kernel bases (affine 64 B, external limbs) -> bases29 (80 B, 29-bit internal limbs)
+//   convert_bases_kernel bases (affine 64 B, external Montgomery R=2^256) -> bases29 (64 B, internal domain rho=2^261)
 //   accumulate_kernel    sorted + bases29 -> buckets[W][nb]  (XYZZ 144 B internal)         <- dominant
 //   reduce_seg_kernel    buckets -> S[W][nseg], T[W][nseg]   (segments of 8 buckets)
 //   reduce_tree_kernel   S, T -> partial[W][K+1]  (one plain sum + K bit-subset sums per window)
@@ -109,7 +109,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 #endif
 
 #if defined(__HIPCC__)
-// 16-byte vector loads/stores of the internal-representation points (80 B affine, 144 B XYZZ).
+// 16-byte vector loads/stores of the internal-representation points (64 B packed affine, 144 B XYZZ).
 template <int QUADS>
 __device__ __forceinline__ void load_quads(const void* p, uint32_t* dst) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
@@ -125,21 +125,16 @@ __device__ __forceinline__ void store_quads(void* p, const uint32_t* src) {
 #pragma unroll
   for (int i = 0; i < QUADS; ++i) q[i] = make_uint4(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
 }
-__device__ __forceinline__ AffI load_affi(const AffI* p) {
-  uint32_t w[20];
-  load_quads<5>(p, w);
-  AffI r;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) { r.x.l[i] = w[i]; r.y.l[i] = w[9 + i]; }
-  r.pad[0] = r.pad[1] = 0;
-  return r;
+__device__ __forceinline__ AffI load_affi(const AffPacked* p) {
+  AffPacked q;
+  q.x = load_u256(&p->x);
+  q.y = load_u256(&p->y);
+  return affi_unpack(q);
 }
-__device__ __forceinline__ void store_affi(AffI* p, const AffI& a) {
-  uint32_t w[20];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) { w[i] = a.x.l[i]; w[9 + i] = a.y.l[i]; }
-  w[18] = w[19] = 0;
-  store_quads<5>(p, w);
+__device__ __forceinline__ void store_affi(AffPacked* p, const AffI& a) {
+  const AffPacked q = affi_pack(a);
+  store_u256(&p->x, q.x);
+  store_u256(&p->y, q.y);
 }
 __device__ __forceinline__ PtI load_pti(const PtI* p) {
   uint32_t w[36];

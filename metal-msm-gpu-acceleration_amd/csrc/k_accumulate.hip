@@ -20,7 +20,7 @@ namespace msm_amd {
 // drained (measured: a 1024-thread plan_kernel workgroup waited 1.4 ms behind 3-wave accumulate waves).
 template <bool LOW_OCC>
 __global__ void __launch_bounds__(64)
-accumulate_kernel(const AffI* __restrict__ bases, const uint32_t* __restrict__ sorted,
+accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,
                   const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
                   const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
                   const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
@@ -123,10 +123,11 @@ combine_big_kernel(const uint32_t* __restrict__ big_list, const PlanCounters* __
   }
 }
 
-void launch_accumulate(hipStream_t st, const Plan& p, const AffI* bases, const SortBuffers& b, PtI* buckets,
-                       PtI* partials, bool low_occupancy) {
+void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
+                       PtI* partials, bool low_occupancy, hipEvent_t before_kernel, hipEvent_t after_kernel) {
   // empty buckets produce no work item: all-zero memory is the identity (Z = 0)
   (void)hipMemsetAsync(buckets, 0, p.total_buckets * sizeof(PtI), st);
+  if (before_kernel) (void)hipEventRecord(before_kernel, st);
   if (low_occupancy) {
     hipLaunchKernelGGL(accumulate_kernel<true>, dim3((unsigned)((p.max_items + 63) / 64)), dim3(64), 0, st, bases,
                        (const uint32_t*)b.sorted, (const uint32_t*)b.bucket_start, (const uint32_t*)b.bucket_size,
@@ -138,6 +139,7 @@ void launch_accumulate(hipStream_t st, const Plan& p, const AffI* bases, const S
                        (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, (const uint2*)b.order,
                        (const PlanCounters*)b.counters, p.n, p.lb, p.CH, buckets, partials);
   }
+  if (after_kernel) (void)hipEventRecord(after_kernel, st);
   // multi_list doubles as big_list storage: its second half (entries max_items/2 ..) is free because a split
   // bucket accounts for at least two items
   uint32_t* big_list = b.multi_list + p.max_items / 2 + 1;

@@ -36,13 +36,13 @@ gen_instance_kernel(uint64_t seed, uint32_t n, int scalars_mont, Affine* __restr
 // External affine bases (64 B, 8 x u32 Montgomery R = 2^256) -> internal 29-bit-limb form (80 B).  One pass
 // per MSM: 2 internal multiplications per point, ~1 % of the accumulation work.
 __global__ void __launch_bounds__(128)
-convert_bases_kernel(const Affine* __restrict__ in, uint32_t n, AffI* __restrict__ out) {
+convert_bases_kernel(const Affine* __restrict__ in, uint32_t n, AffPacked* __restrict__ out) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   store_affi(&out[t], affi_from_ext(load_affine(&in[t])));
 }
 
-void launch_convert_bases(hipStream_t st, const Affine* in, uint32_t n, AffI* out) {
+void launch_convert_bases(hipStream_t st, const Affine* in, uint32_t n, AffPacked* out) {
   hipLaunchKernelGGL(convert_bases_kernel, dim3((n + 127) / 128), dim3(128), 0, st, in, n, out);
 }
 

@@ -56,8 +56,8 @@ void launch_be32_to_le(hipStream_t st, const uint32_t* in, size_t words, uint32_
 void launch_ark_affine_to_affine(hipStream_t st, const uint8_t* in, uint32_t n, Affine* out);
 
 // k_accumulate.hip
-void launch_accumulate(hipStream_t st, const Plan& p, const AffI* bases, const SortBuffers& b, PtI* buckets,
-                       PtI* partials, bool low_occupancy);
+void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
+                       PtI* partials, bool low_occupancy, hipEvent_t before_kernel, hipEvent_t after_kernel);
 
 // k_reduce.hip
 int reduce_set_attributes(const char** failed);
@@ -65,7 +65,7 @@ void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, PtI* S, Pt
 
 // k_misc.hip
 void launch_projective_to_affine(hipStream_t st, const Jacobian* in, uint32_t n, Affine* out);
-void launch_convert_bases(hipStream_t st, const Affine* in, uint32_t n, AffI* out);
+void launch_convert_bases(hipStream_t st, const Affine* in, uint32_t n, AffPacked* out);
 void launch_gen_instance(hipStream_t st, uint64_t seed, uint32_t n, int scalars_mont, Affine* bases, u256* scalars);
 
 // k_stage.hip

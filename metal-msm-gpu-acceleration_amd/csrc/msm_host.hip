@@ -34,7 +34,7 @@ struct DeviceBuf {
   size_t cap = 0;
 };
 
-enum { EV_START = 0, EV_CONVERT, EV_DIGITS, EV_SORT, EV_ACC, EV_REDUCE, EV_COUNT };
+enum { EV_START = 0, EV_CONVERT, EV_DIGITS, EV_SORT, EV_ACC, EV_REDUCE, EV_ACC_K0, EV_ACC_K1, EV_COUNT };
 
 struct InstanceSlot {
   hipEvent_t ev[EV_COUNT];
@@ -364,7 +364,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   if ((rc = ensure(ctx, w.order, p.max_items * sizeof(uint2)))) return rc;
   if ((rc = ensure(ctx, w.multi_list, p.max_items * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.counters, sizeof(PlanCounters)))) return rc;
-  if ((rc = ensure(ctx, w.bases29, n * sizeof(AffI)))) return rc;
+  if ((rc = ensure(ctx, w.bases29, n * sizeof(AffPacked)))) return rc;
   if ((rc = ensure(ctx, w.buckets, p.total_buckets * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.item_partials, p.max_items * sizeof(PtI)))) return rc;
   SortBuffers sb{};
@@ -392,7 +392,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   const Affine* pts = nullptr;
   int sc_mont = 0;
   if ((rc = convert_inputs(ctx, w, scalar_layout, point_layout, d_scalars, d_points, n, &sc, &sc_mont, &pts))) return rc;
-  launch_convert_bases(st, pts, p.n, (AffI*)w.bases29.p);   // 8 x u32 limbs -> 9 x 29-bit internal limbs
+  launch_convert_bases(st, pts, p.n, (AffPacked*)w.bases29.p);   // 8 x u32 limbs -> 9 x 29-bit internal limbs
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_CONVERT], st));
 
   launch_digits(st, p, sc, sc_mont, sb.digits);
@@ -401,7 +401,8 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   launch_sort(st, p, sb);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_SORT], st));
 
-  launch_accumulate(st, p, (const AffI*)w.bases29.p, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p, false);
+  launch_accumulate(st, p, (const AffPacked*)w.bases29.p, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p, false,
+                    slot.ev[EV_ACC_K0], slot.ev[EV_ACC_K1]);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
 
   // window reduction + result copy: on the side stream, so that the main stream can start the next instance
@@ -424,7 +425,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
 
 void accumulate_timings(msm_amd_ctx* ctx, InstanceSlot& s, const Plan& p, float final_ms, size_t n_inst) {
   float ms[EV_COUNT] = {0};
-  for (int i = 1; i < EV_COUNT; ++i) {
+  for (int i = 1; i <= EV_REDUCE; ++i) {
     float t = 0;
     if (hipEventElapsedTime(&t, s.ev[i - 1], s.ev[i]) != hipSuccess) {
       (void)hipGetLastError();
@@ -439,6 +440,14 @@ void accumulate_timings(msm_amd_ctx* ctx, InstanceSlot& s, const Plan& p, float 
   T.sort_ms += ms[EV_SORT] * inv;
   T.accumulate_ms += ms[EV_ACC] * inv;
   T.reduce_ms += ms[EV_REDUCE] * inv;
+  {
+    float t = 0;
+    if (hipEventElapsedTime(&t, s.ev[EV_ACC_K0], s.ev[EV_ACC_K1]) != hipSuccess) {
+      (void)hipGetLastError();
+      t = 0;
+    }
+    T.accumulate_kernel_ms += t * inv;
+  }
   T.final_ms += final_ms * inv;
   T.total_gpu_ms += (ms[EV_CONVERT] + ms[EV_DIGITS] + ms[EV_SORT] + ms[EV_ACC] + ms[EV_REDUCE]) * inv;
   T.n = p.n;

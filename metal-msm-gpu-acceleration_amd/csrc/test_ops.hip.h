@@ -37,7 +37,7 @@ MSM_HD void run_test_op(int op, const u256* a, const u256* b, u256* out, uint32_
           case 18: ri = Fq29::norm(Fq29::sub<K8E31>(xi, y3)); break;
           case 19: ri = Fq29::norm(Fq29::sub<K16E30>(xi, yi)); break;
           case 20: ri = Fq29::norm(Fq29::sub<K16E31>(xi, y3)); break;
-          case 21: ri = xi; break;
+          case 21: ri = Fq29::unpack256(Fq29::pack_canonical(xi)); break;   // incl. the 32-byte storage form
         }
         r = Fq29::to_ext(ri);
       }
