@@ -108,6 +108,20 @@ int msm_amd_msm(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const voi
 int msm_amd_msm_batch(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
                       const void* const* scalars, const void* const* points, const size_t* n, void* out);
 
+/* ---- hybrid front-end ----------------------------------------------------------------------- */
+/* msm_best::<G1Affine, ..>(scalars, points) -> G1 (msm.rs:424-445): filter_zeros (drop zero scalars when at
+ * least 30 % of them are zero, msm.rs:448-507, done here by a device compaction) and then the MSM.  The
+ * reference sends n < 2^17 to halo2curves on the CPU because its Metal path is slower there; this library
+ * stays on the GPU for every n (no CPU fallback is linked behind this entry point).  h2c layouts. */
+int msm_amd_msm_best(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n, void* out96);
+/* gpu_with_cpu (msm.rs:366-421): the first split_at points go to the GPU, the rest to a multi-threaded host
+ * bucket method (cpu_threads <= 0: all hardware threads); the two results are added.  h2c layouts. */
+int msm_amd_gpu_with_cpu(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n, size_t split_at,
+                         int cpu_threads, void* out96);
+/* The reference's split policy (msm.rs:377-383): n/3 below 2^18, n/2 below 2^20, else 2n/3 go to the GPU.
+ * On MI355X the throughput-optimal split is split_at = n; the policy is kept for parity. */
+size_t msm_amd_reference_split(size_t n);
+
 /* ---- whole-MSM entry points: inputs already resident in device memory ------------------------ */
 /* Same as msm_amd_msm / msm_amd_msm_batch but scalars/points are device pointers on ctx's device
  * (the reference re-uploads and re-converts per call, msm.rs:152-153; an SRS is uploaded once here). */

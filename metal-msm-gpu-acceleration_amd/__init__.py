@@ -31,7 +31,8 @@ def op_is_point(op):
 EXPORTS = [
     "msm_amd_init", "msm_amd_init_reusable", "msm_amd_get_global", "msm_amd_destroy", "msm_amd_strerror",
     "msm_amd_last_error", "msm_amd_set_window_size", "msm_amd_auto_window_size", "msm_amd_gpu_msm_h2c",
-    "msm_amd_metal_msm_ark", "msm_amd_msm", "msm_amd_msm_batch", "msm_amd_msm_device",
+    "msm_amd_metal_msm_ark", "msm_amd_msm", "msm_amd_msm_batch", "msm_amd_msm_best", "msm_amd_gpu_with_cpu",
+    "msm_amd_reference_split", "msm_amd_msm_device",
     "msm_amd_msm_batch_device", "msm_amd_device_alloc", "msm_amd_device_free", "msm_amd_copy_to_device",
     "msm_amd_copy_to_host", "msm_amd_stream", "msm_amd_synchronize", "msm_amd_generate_instance",
     "msm_amd_prepare_buckets_indices", "msm_amd_sort_buckets_indices", "msm_amd_bucket_wise_accumulation",
@@ -83,6 +84,10 @@ def _lib():
         L.msm_amd_msm.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
         L.msm_amd_msm_batch.argtypes = [c_void_p, c_int, c_int, c_size_t, POINTER(c_void_p), POINTER(c_void_p),
                                         POINTER(c_size_t), c_void_p]
+        L.msm_amd_msm_best.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.msm_amd_gpu_with_cpu.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p]
+        L.msm_amd_reference_split.argtypes = [c_size_t]
+        L.msm_amd_reference_split.restype = c_size_t
         L.msm_amd_msm_device.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
         L.msm_amd_msm_batch_device.argtypes = [c_void_p, c_int, c_int, c_size_t, POINTER(c_void_p),
                                                POINTER(c_void_p), POINTER(c_size_t), c_void_p]
@@ -295,6 +300,26 @@ def gpu_msm_h2c(scalars: bytes, points: bytes, config: MsmConfig | None = None) 
     cfg = config or setup_metal_state_reusable()
     out = ctypes.create_string_buffer(96)
     cfg._check(_lib().msm_amd_gpu_msm_h2c(cfg.h, scalars, points, n, out))
+    return out.raw
+
+
+def msm_best(scalars: bytes, points: bytes, config: MsmConfig | None = None) -> bytes:
+    """msm_best (msm.rs:424-445): zero-scalar filtering + MSM."""
+    n = min(len(scalars) // 32, len(points) // 64)
+    cfg = config or setup_metal_state_reusable()
+    out = ctypes.create_string_buffer(96)
+    cfg._check(_lib().msm_amd_msm_best(cfg.h, scalars, points, n, out))
+    return out.raw
+
+
+def gpu_with_cpu(scalars: bytes, points: bytes, config: MsmConfig | None = None, split_at=None, cpu_threads=0) -> bytes:
+    """gpu_with_cpu (msm.rs:366-421); split_at defaults to the reference's policy."""
+    n = min(len(scalars) // 32, len(points) // 64)
+    cfg = config or setup_metal_state_reusable()
+    if split_at is None:
+        split_at = _lib().msm_amd_reference_split(n)
+    out = ctypes.create_string_buffer(96)
+    cfg._check(_lib().msm_amd_gpu_with_cpu(cfg.h, scalars, points, n, split_at, cpu_threads, out))
     return out.raw
 
 

@@ -159,6 +159,44 @@ pad_buckets_kernel(const Jacobian* __restrict__ in, uint32_t bs, uint32_t W, uin
 }
 
 // ------------------------------------------------------------------------------------------------
+// filter_zeros (src/metal/msm.rs:448-507): drop (scalar, point) pairs whose scalar is zero.  The reference does
+// it on the CPU with rayon when at least 30 % of the scalars are zero.  Three kernels: per-block count of
+// non-zero scalars, exclusive scan of the block counts (linear_scan_kernel), order-preserving scatter.
+constexpr int kFilterThreads = 1024;
+
+__global__ void __launch_bounds__(kFilterThreads)
+filter_count_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t scratch[17];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t nz = 0;
+  if (t < n) nz = u256_is_zero(load_u256(&scalars[t])) ? 0u : 1u;
+  uint32_t total;
+  (void)block_exclusive_scan(nz, scratch, &total);
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kFilterThreads)
+filter_scatter_kernel(const u256* __restrict__ scalars, const Affine* __restrict__ points, uint32_t n,
+                      const uint32_t* __restrict__ block_offsets, u256* __restrict__ out_scalars,
+                      Affine* __restrict__ out_points) {
+  __shared__ uint32_t scratch[17];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  u256 k = u256_zero();
+  uint32_t nz = 0;
+  if (t < n) {
+    k = load_u256(&scalars[t]);
+    nz = u256_is_zero(k) ? 0u : 1u;
+  }
+  uint32_t total;
+  const uint32_t rank = block_exclusive_scan(nz, scratch, &total);
+  if (nz) {
+    const uint32_t pos = block_offsets[blockIdx.x] + rank;
+    store_u256(&out_scalars[pos], k);
+    store_affine(&out_points[pos], load_affine(&points[t]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Batched single-op kernel (bodies in test_ops.hip.h).
 __global__ void __launch_bounds__(64)
 test_op_kernel(int op, const u256* __restrict__ a, const u256* __restrict__ b, u256* __restrict__ out,
@@ -201,6 +239,17 @@ void launch_ref_accumulate(hipStream_t st, const uint2* pairs, size_t n_pairs, c
 void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t lb, PtI* out) {
   const size_t total = (size_t)W << lb;
   hipLaunchKernelGGL(pad_buckets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, bs, W, lb, out);
+}
+
+// block_counts: ceil(n / 1024) + 1 words; after the call block_counts[nblocks] holds the number of survivors.
+void launch_filter_zeros(hipStream_t st, const u256* scalars, const Affine* points, uint32_t n, uint32_t* block_counts,
+                         u256* out_scalars, Affine* out_points) {
+  const uint32_t nblocks = (n + kFilterThreads - 1) / kFilterThreads;
+  hipLaunchKernelGGL(filter_count_kernel, dim3(nblocks), dim3(kFilterThreads), 0, st, scalars, n, block_counts);
+  (void)hipMemsetAsync(block_counts + nblocks, 0, 4, st);
+  hipLaunchKernelGGL(linear_scan_kernel, dim3(1), dim3(1024), 0, st, block_counts, (size_t)nblocks + 1);
+  hipLaunchKernelGGL(filter_scatter_kernel, dim3(nblocks), dim3(kFilterThreads), 0, st, scalars, points, n,
+                     (const uint32_t*)block_counts, out_scalars, out_points);
 }
 
 void launch_test_op(hipStream_t st, int op, const u256* a, const u256* b, u256* out, uint32_t count) {

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/msm_amd.h"
@@ -681,6 +682,87 @@ int msm_amd_gpu_msm_h2c(msm_amd_ctx* ctx, const void* scalars, const void* point
 
 int msm_amd_metal_msm_ark(msm_amd_ctx* ctx, const void* points, const void* scalars, size_t n, void* out96) {
   return msm_amd_msm(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_ARK_PROJECTIVE, scalars, points, n, out96);
+}
+
+// ---- hybrid front-end (src/metal/msm.rs:366-507) ---------------------------------------------------------
+size_t msm_amd_reference_split(size_t n) {
+  // gpu_with_cpu's split_at (msm.rs:377-383): the GPU gets the first n/3, n/2 or 2n/3 points
+  if (n < ((size_t)1 << 18)) return n / 3;
+  if (n < ((size_t)1 << 20)) return n / 2;
+  return n * 2 / 3;
+}
+
+int msm_amd_gpu_with_cpu(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n, size_t split_at,
+                         int cpu_threads, void* out96) {
+  if (!ctx || !scalars || !points || !out96 || n == 0 || split_at > n)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "bad gpu_with_cpu arguments");
+  if (cpu_threads <= 0) cpu_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+  const u256* sc = (const u256*)scalars;
+  const Affine* pt = (const Affine*)points;
+  // CPU share on host threads (the reference waits for the GPU sort first because its sort borrows the CPU,
+  // msm.rs:403-415; here the host cores are free from the start)
+  Jacobian cpu_res = jac_identity();
+  std::thread cpu_thread;
+  const size_t n_cpu = n - split_at;
+  if (n_cpu) cpu_thread = std::thread([&] { cpu_res = host_msm(sc + split_at, 1, pt + split_at, n_cpu, cpu_threads); });
+  Jacobian gpu_res = jac_identity();
+  int rc = MSM_AMD_OK;
+  if (split_at) {
+    uint8_t buf[96];
+    rc = msm_amd_msm(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, scalars, points, split_at, buf);
+    if (rc == MSM_AMD_OK) std::memcpy(&gpu_res, buf, 96);
+  }
+  if (n_cpu) cpu_thread.join();
+  if (rc) return rc;
+  const Jacobian sum = normalise(jac_add(gpu_res, cpu_res));   // msm.rs:418-419
+  std::memcpy(out96, &sum, 96);
+  return MSM_AMD_OK;
+}
+
+int msm_amd_msm_best(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n, void* out96) {
+  if (!ctx || !scalars || !points || !out96 || n == 0 || n > 0x7FFFFFFFull)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "bad msm_best arguments");
+  std::unique_lock<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  const uint32_t nblocks = (uint32_t)((n + 1023) / 1024);
+  if ((rc = ensure(ctx, ctx->scratch_b, n * 32))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_c, n * 64))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_a, ((size_t)nblocks + 1) * 4 + n * 96))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, points, n * 64, hipMemcpyHostToDevice, st));
+  // filter_zeros (msm.rs:448-507): compact on the device, keep the compaction only if >= 30 % were zero
+  uint32_t* counts = (uint32_t*)ctx->scratch_a.p;
+  u256* f_sc = (u256*)((uint8_t*)ctx->scratch_a.p + (((size_t)nblocks + 1) * 4 + 63) / 64 * 64);
+  Affine* f_pt = (Affine*)(f_sc + n);
+  if ((rc = ensure(ctx, ctx->scratch_a, (((size_t)nblocks + 1) * 4 + 63) / 64 * 64 + n * 96))) return rc;
+  counts = (uint32_t*)ctx->scratch_a.p;
+  f_sc = (u256*)((uint8_t*)ctx->scratch_a.p + (((size_t)nblocks + 1) * 4 + 63) / 64 * 64);
+  f_pt = (Affine*)(f_sc + n);
+  launch_filter_zeros(st, (const u256*)ctx->scratch_b.p, (const Affine*)ctx->scratch_c.p, (uint32_t)n, counts, f_sc,
+                      f_pt);
+  HIP_TRY(ctx, hipGetLastError());
+  uint32_t survivors = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&survivors, counts + nblocks, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  const double zero_ratio = (double)(n - survivors) / (double)n;
+  const void* ds = ctx->scratch_b.p;
+  const void* dp = ctx->scratch_c.p;
+  size_t m = n;
+  if (zero_ratio >= 0.30) {   // msm.rs:470
+    ds = f_sc;
+    dp = f_pt;
+    m = survivors;
+  }
+  if (m == 0) {   // every scalar is zero: the sum is the identity
+    const Jacobian id = jac_identity();
+    std::memcpy(out96, &id, 96);
+    return MSM_AMD_OK;
+  }
+  // The reference sends n < 2^17 to the CPU because its Metal path loses there (msm.rs:440-444); on MI355X the
+  // GPU path wins for every n that is worth a call, and no CPU MSM fallback is linked behind this entry point.
+  return run_batch_device(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, 1, &ds, &dp, &m, out96);
 }
 
 int msm_amd_msm_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,

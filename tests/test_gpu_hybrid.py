@@ -1,0 +1,48 @@
+"""Hybrid front-end (src/metal/msm.rs:366-507): msm_best with filter_zeros, gpu_with_cpu with the reference's
+split policy.  Mirrors test_gpu_cpu_correctness_medium_sample_h2c / test_best_msm_correctness_medium_sample_h2c
+(msm.rs:618-689) at sizes the CPU oracle finishes in seconds."""
+import random
+
+import pytest
+
+from oracle import bn254_ref as o
+from oracle import c_oracle as co
+from helpers import h2c_instance_bytes, small_instance
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_split_policy(msm_pkg):
+    L = msm_pkg.lib()
+    assert L.msm_amd_reference_split(3000) == 1000                    # n/3 below 2^18 (msm.rs:377-378)
+    assert L.msm_amd_reference_split(1 << 18) == 1 << 17              # n/2 below 2^20
+    assert L.msm_amd_reference_split(1 << 20) == (1 << 20) * 2 // 3   # 2n/3 from 2^20
+
+
+@pytest.mark.parametrize("zero_frac", [0.0, 0.29, 0.31, 0.9, 1.0])
+def test_msm_best_filter_zeros(cfg, msm_pkg, zero_frac):
+    """filter_zeros threshold 30 % (msm.rs:470): below it the inputs pass unchanged, above it zero scalars and
+    their points are compacted away; the result is the same MSM either way."""
+    rng = random.Random(int(zero_frac * 100))
+    n = 3000
+    pts, sc = small_instance(11, 200)
+    pts = [pts[i % 200] for i in range(n)]
+    sc = [rng.randrange(1, o.R_ORDER) for _ in range(n)]
+    nz = int(round(zero_frac * n))
+    for i in rng.sample(range(n), nz):
+        sc[i] = 0
+    sb, pb = h2c_instance_bytes(pts, sc)
+    out = msm_pkg.msm_best(sb, pb, cfg)
+    expect = co.msm_best(sb, pb, n, 2)
+    assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(expect)
+    if zero_frac == 1.0:
+        assert o.decode_jacobian_mont_le(out) is None
+
+
+@pytest.mark.parametrize("n,split", [(1000, None), (1000, 0), (1000, 1000), (4097, 1234)])
+def test_gpu_with_cpu(cfg, msm_pkg, n, split):
+    pb, sb = co.gen_instance(o.SEED_BASE + 50, n)
+    out = msm_pkg.gpu_with_cpu(sb, pb, cfg, split_at=split, cpu_threads=2)
+    assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(co.msm_best(sb, pb, n, 2))
+    z = int.from_bytes(out[64:96], "little")
+    assert z in (0, o.MONT_R % o.P)
