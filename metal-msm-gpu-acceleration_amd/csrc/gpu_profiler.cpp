@@ -6,12 +6,12 @@
 //
 // Modes (gpu_profiler.rs:143-172)
 //   gpu       metal::msm::gpu_msm_h2c      -> msm_amd_gpu_msm_h2c (host buffers, upload included)
-//   gpu_cpu   metal::msm::gpu_with_cpu     -> NOT built yet: reported as an error
-//   best_gpu  metal::msm_best              -> NOT built yet (row N1)
-//   cpu       halo2curves::msm::msm_best   -> needs the CPU oracle, which is test infrastructure and is
-//                                             deliberately not linked into product binaries; use bench.py's
-//                                             cpu_baseline leg or tests instead
-//   check     gpu vs cpu equality          -> same restriction as `cpu`
+//   gpu_cpu   metal::msm::gpu_with_cpu     -> msm_amd_gpu_with_cpu with the reference's split policy
+//   best_gpu  metal::msm_best              -> msm_amd_msm_best (device filter_zeros + MSM)
+//   cpu       halo2curves::msm::msm_best   -> the library's own host bucket method (the CPU half of
+//                                             gpu_with_cpu with split_at = 0); NOT halo2curves and not the
+//                                             test oracle -- bench.py's cpu_baseline leg times the oracle
+//   check     gpu_with_cpu vs cpu equality -> byte comparison of the two normalised 96-byte results
 // Extra mode
 //   gpu_resident   inputs generated once on the device (msm_amd_generate_instance) and kept resident: the
 //                  configuration the headline metric is quoted on.
@@ -60,16 +60,8 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "[ERROR] bad arguments\n");
     return 1;
   }
-  if (mode == "cpu" || mode == "check") {
-    std::fprintf(stderr, "[ERROR] RUN_MODE %s needs the CPU oracle, which is not linked into product binaries; "
-                         "run `python bench.py` (cpu_baseline) or the tests\n", mode.c_str());
-    return 1;
-  }
-  if (mode == "gpu_cpu" || mode == "best_gpu") {
-    std::fprintf(stderr, "[ERROR] RUN_MODE %s (hybrid front-end, msm.rs:366-445) is not built yet\n", mode.c_str());
-    return 1;
-  }
-  if (mode != "gpu" && mode != "gpu_resident") {
+  const bool host_inputs = mode == "gpu" || mode == "gpu_cpu" || mode == "best_gpu" || mode == "cpu" || mode == "check";
+  if (!host_inputs && mode != "gpu_resident") {
     std::fprintf(stderr, "[ERROR] Invalid RUN_MODE: %s\n", mode.c_str());   // gpu_profiler.rs:167-170
     return 1;
   }
@@ -90,7 +82,7 @@ int main(int argc, char** argv) {
     if ((st = msm_amd_device_alloc(ctx, n * 32, &d_sc[j]))) die(ctx, st, "device_alloc");
     if ((st = msm_amd_generate_instance(ctx, seed + j, n, 1, d_pts[j], d_sc[j]))) die(ctx, st, "generate_instance");
   }
-  if (mode == "gpu") {
+  if (host_inputs) {
     h_pts.resize(num_instances);
     h_sc.resize(num_instances);
     for (unsigned j = 0; j < num_instances; ++j) {
@@ -117,6 +109,26 @@ int main(int argc, char** argv) {
           st = msm_amd_gpu_msm_h2c(ctx, h_sc[j].data(), h_pts[j].data(), n, out.data() + (size_t)j * 96);
           if (st) die(ctx, st, "gpu_msm_h2c");
         }
+      }
+    } else if (mode == "gpu_cpu" || mode == "best_gpu" || mode == "cpu" || mode == "check") {
+      for (unsigned j = 0; j < num_instances; ++j) {   // run_selected_msm (gpu_profiler.rs:143-172)
+        uint8_t* o = out.data() + (size_t)j * 96;
+        if (mode == "gpu_cpu") {
+          st = msm_amd_gpu_with_cpu(ctx, h_sc[j].data(), h_pts[j].data(), n, msm_amd_reference_split(n), 0, o);
+        } else if (mode == "best_gpu") {
+          st = msm_amd_msm_best(ctx, h_sc[j].data(), h_pts[j].data(), n, o);
+        } else if (mode == "cpu") {
+          st = msm_amd_gpu_with_cpu(ctx, h_sc[j].data(), h_pts[j].data(), n, 0, 0, o);
+        } else {
+          uint8_t ref[96];
+          st = msm_amd_gpu_with_cpu(ctx, h_sc[j].data(), h_pts[j].data(), n, msm_amd_reference_split(n), 0, o);
+          if (!st) st = msm_amd_gpu_with_cpu(ctx, h_sc[j].data(), h_pts[j].data(), n, 0, 0, ref);
+          if (!st && std::memcmp(o, ref, 96) != 0) {
+            std::fprintf(stderr, "[ERROR] check failed: gpu_with_cpu != cpu for instance %u\n", j);   // :161-165
+            return 1;
+          }
+        }
+        if (st) die(ctx, st, mode.c_str());
       }
     } else {
       for (unsigned j = 0; j < num_instances; ++j) { sp[j] = d_sc[j]; pp[j] = d_pts[j]; }
