@@ -129,7 +129,8 @@ MSM_HD PtI pti_double(const PtI& p) {   // p not the identity
 }
 
 // ---- fast paths -------------------------------------------------------------------------------------
-// p + q, p XYZZ (not identity), q affine (not identity).  madd-2008-s, 8M + 2S.
+// p + q, p XYZZ (not identity), q affine (not identity).  madd-2008-s, 8M + 2S with the two products of Y3
+// sharing one Montgomery reduction (7 full multiplications + 1 product-only + 2 squarings).
 MSM_HD PtI pti_madd(const PtI& p, const AffI& q) {
   const fe29 U2 = Fq29::mul(q.x, p.zz);
   const fe29 S2 = Fq29::mul(q.y, p.zzz);
@@ -148,7 +149,7 @@ MSM_HD PtI pti_madd(const PtI& p, const AffI& q) {
   PtI r;
   r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.5 p
   const fe29 T = Fq29::norm(Fq29::sub<K16E30>(Q, r.x));                                   // < 17.2 p
-  r.y = Fq29::norm(Fq29::sub<K4E30>(Fq29::mul(R, T), Fq29::mul(p.y, PPP)));              // < 6 p
+  r.y = Fq29::mul2(R, T, p.y, Fq29::neg(PPP));   // R*T - Y1*PPP in one reduction              // < 1.2 p
   r.zz = Fq29::mul(p.zz, PP);
   r.zzz = Fq29::mul(p.zzz, PPP);
   return r;
@@ -175,7 +176,7 @@ MSM_HD PtI pti_add_nz(const PtI& p, const PtI& q) {
   PtI r;
   r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.2 p
   const fe29 T = Fq29::norm(Fq29::sub<K16E30>(Q, r.x));                                   // < 17.1 p
-  r.y = Fq29::norm(Fq29::sub<K4E30>(Fq29::mul(R, T), Fq29::mul(S1, PPP)));               // < 5.6 p
+  r.y = Fq29::mul2(R, T, S1, Fq29::neg(PPP));    // R*T - S1*PPP in one reduction              // < 1.2 p
   r.zz = Fq29::mul(Fq29::mul(p.zz, q.zz), PP);
   r.zzz = Fq29::mul(Fq29::mul(p.zzz, q.zzz), PPP);
   return r;

@@ -144,6 +144,25 @@ struct Fq29 {
     return reduce_columns(A);
   }
 
+  // (a*b + c*d)*rho^-1 with ONE Montgomery reduction: 81 + 81 + 81 limb products instead of 2 x (81 + 81).
+  // All four operands must be normalised (limbs <= 2^29 + 8) so that a column of 18 + 9 products stays
+  // below 2^64.  Used for Y3 = R*T - Y1*PPP with d = -PPP.
+  MSM_HD static fe29 mul2(const fe29& a, const fe29& b, const fe29& c, const fe29& d) {
+    uint64_t A[17];
+    MSM_UNROLL for (int k = 0; k < 17; ++k) {
+      uint64_t s = 0;
+      MSM_UNROLL for (int i = 0; i < 9; ++i) {
+        const int j = k - i;
+        if (j >= 0 && j < 9) {
+          s += (uint64_t)a.l[i] * b.l[j];
+          s += (uint64_t)c.l[i] * d.l[j];
+        }
+      }
+      A[k] = s;
+    }
+    return reduce_columns(A);
+  }
+
   // a*a*rho^-1: 45 + 81 limb products (cross products use the doubled operand).
   MSM_HD static fe29 sqr(const fe29& a) {
     uint32_t d[9];
