@@ -35,7 +35,7 @@ struct DeviceBuf {
   size_t cap = 0;
 };
 
-enum { EV_START = 0, EV_CONVERT, EV_DIGITS, EV_SORT, EV_ACC, EV_REDUCE, EV_ACC_K0, EV_ACC_K1, EV_COUNT };
+enum { EV_START = 0, EV_CONVERT, EV_DIGITS, EV_SORT, EV_ACC_S, EV_ACC, EV_RED_S, EV_REDUCE, EV_ACC_K0, EV_ACC_K1, EV_COUNT };
 
 struct InstanceSlot {
   hipEvent_t ev[EV_COUNT];
@@ -55,9 +55,10 @@ struct InstanceSlot {
 struct Workspace {
   DeviceBuf digits, coarse_cnt, region_start, tmp_idx, tmp_fine, bsize, bstart, istart, win_items, size_bins, sorted,
       order, multi_list, counters, bases29, buckets, item_partials, S, T, partial, conv_scalars, conv_points, conv_tmp;
-  hipEvent_t acc_done = nullptr;      // main stream: buckets of this workspace are complete
-  hipEvent_t reduce_done = nullptr;   // side stream: buckets / partial of this workspace are free again
-  bool reduce_pending = false;
+  hipEvent_t front_done = nullptr;    // front stream: sorted indices / work items of this workspace are ready
+  hipEvent_t acc_done = nullptr;      // main stream: buckets of this workspace are complete (incl. combine)
+  hipEvent_t reduce_done = nullptr;   // reduce stream: buckets / partial of this workspace are free again
+  bool acc_pending = false, reduce_pending = false;
 };
 
 constexpr int kWorkspaces = 2;
@@ -66,7 +67,9 @@ struct msm_amd_ctx {
   int device = 0;
   hipStream_t stream = nullptr;          // main stream: conversion, digits, sort, accumulate; stage entry points
   hipStream_t reduce_stream = nullptr;   // side stream: window reduction + copy of the partial points
-  bool overlap_reduce = true;            // MSM_AMD_OVERLAP_REDUCE=0 puts everything on the main stream
+  hipStream_t front_stream = nullptr;    // side stream: conversion, digits, sort, work-item planning
+  bool overlap_reduce = true;            // MSM_AMD_OVERLAP_REDUCE=0 puts the reduction on the main stream
+  bool overlap_front = true;             // MSM_AMD_OVERLAP_FRONT=0 puts the front end on the main stream
   Workspace ws[kWorkspaces];
   std::mutex mu;
   std::string last_error;
@@ -261,10 +264,9 @@ int slot_prepare(msm_amd_ctx* ctx, InstanceSlot& s, size_t partial_count) {
 
 // Bring inputs to the native device layout (affine 64 B Montgomery LE; scalars 32 B LE).
 // On return *scalars_native / *points_native point to device memory valid until the next call.
-int convert_inputs(msm_amd_ctx* ctx, Workspace& w, int scalar_layout, int point_layout, const void* d_scalars,
+int convert_inputs(msm_amd_ctx* ctx, Workspace& w, hipStream_t st, int scalar_layout, int point_layout, const void* d_scalars,
                    const void* d_points, size_t n, const u256** scalars_native, int* scalars_mont,
                    const Affine** points_native) {
-  hipStream_t st = ctx->stream;
   switch (scalar_layout) {
     case MSM_AMD_SCALAR_MONT_LE:
       *scalars_native = (const u256*)d_scalars;
@@ -384,56 +386,70 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   sb.multi_list = (uint32_t*)w.multi_list.p;
   sb.counters = (PlanCounters*)w.counters.p;
 
-  if (w.reduce_pending) {   // the previous user of this workspace may still be reducing its buckets
-    HIP_TRY(ctx, hipStreamWaitEvent(st, w.reduce_done, 0));
-    w.reduce_pending = false;
+  // Three streams, two workspaces (instance i uses workspace i % 2):
+  //   front  : conversion, digits, sort, planning of instance i      -- may run while instance i-1 accumulates
+  //   main   : accumulate + combine of instance i                    -- needs front(i) and reduce(i-2)
+  //   reduce : window reduction + copy of instance i                 -- needs main(i)
+  hipStream_t fs = ctx->overlap_front ? ctx->front_stream : st;
+  hipStream_t rs = ctx->overlap_reduce ? ctx->reduce_stream : st;
+  if (w.acc_pending && fs != st) {   // the previous accumulate/combine in this workspace still reads its plan
+    HIP_TRY(ctx, hipStreamWaitEvent(fs, w.acc_done, 0));
   }
-  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_START], st));
+  w.acc_pending = false;
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_START], fs));
   const u256* sc = nullptr;
   const Affine* pts = nullptr;
   int sc_mont = 0;
-  if ((rc = convert_inputs(ctx, w, scalar_layout, point_layout, d_scalars, d_points, n, &sc, &sc_mont, &pts))) return rc;
-  launch_convert_bases(st, pts, p.n, (AffPacked*)w.bases29.p);   // 8 x u32 limbs -> 9 x 29-bit internal limbs
-  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_CONVERT], st));
-
-  launch_digits(st, p, sc, sc_mont, sb.digits);
-  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_DIGITS], st));
-
-  launch_sort(st, p, sb);
-  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_SORT], st));
-
-  launch_accumulate(st, p, (const AffPacked*)w.bases29.p, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p, false,
-                    slot.ev[EV_ACC_K0], slot.ev[EV_ACC_K1]);
-  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
-
-  // window reduction + result copy: on the side stream, so that the main stream can start the next instance
-  hipStream_t rs = ctx->overlap_reduce ? ctx->reduce_stream : st;
-  if (ctx->overlap_reduce) {
-    HIP_TRY(ctx, hipEventRecord(w.acc_done, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(rs, w.acc_done, 0));
+  if ((rc = convert_inputs(ctx, w, fs, scalar_layout, point_layout, d_scalars, d_points, n, &sc, &sc_mont, &pts)))
+    return rc;
+  launch_convert_bases(fs, pts, p.n, (AffPacked*)w.bases29.p);   // external 8 x u32 -> packed internal domain
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_CONVERT], fs));
+  launch_digits(fs, p, sc, sc_mont, sb.digits);
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_DIGITS], fs));
+  launch_sort(fs, p, sb);
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_SORT], fs));
+  if (fs != st) {
+    HIP_TRY(ctx, hipEventRecord(w.front_done, fs));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, w.front_done, 0));
   }
+  if (w.reduce_pending) {   // the previous user of this workspace may still be reducing its buckets
+    if (rs != st) HIP_TRY(ctx, hipStreamWaitEvent(st, w.reduce_done, 0));
+    w.reduce_pending = false;
+  }
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC_S], st));
+  launch_accumulate(st, p, (const AffPacked*)w.bases29.p, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p,
+                    ctx->overlap_front, slot.ev[EV_ACC_K0], slot.ev[EV_ACC_K1]);
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
+  HIP_TRY(ctx, hipEventRecord(w.acc_done, st));
+  w.acc_pending = true;
+
+  if (rs != st) HIP_TRY(ctx, hipStreamWaitEvent(rs, w.acc_done, 0));
+  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_RED_S], rs));
   if ((rc = enqueue_reduce(ctx, w, rs, p, (const PtI*)w.buckets.p))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial, w.partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_REDUCE], rs));
-  if (ctx->overlap_reduce) {
-    HIP_TRY(ctx, hipEventRecord(w.reduce_done, rs));
-    w.reduce_pending = true;
-  }
+  HIP_TRY(ctx, hipEventRecord(w.reduce_done, rs));
+  w.reduce_pending = true;
   HIP_TRY(ctx, hipGetLastError());
   return MSM_AMD_OK;
 }
 
 void accumulate_timings(msm_amd_ctx* ctx, InstanceSlot& s, const Plan& p, float final_ms, size_t n_inst) {
-  float ms[EV_COUNT] = {0};
-  for (int i = 1; i <= EV_REDUCE; ++i) {
+  auto span = [&](int a, int b) {
     float t = 0;
-    if (hipEventElapsedTime(&t, s.ev[i - 1], s.ev[i]) != hipSuccess) {
+    if (hipEventElapsedTime(&t, s.ev[a], s.ev[b]) != hipSuccess) {
       (void)hipGetLastError();
       t = 0;
     }
-    ms[i] = t;
-  }
+    return t;
+  };
+  float ms[EV_COUNT] = {0};
+  ms[EV_CONVERT] = span(EV_START, EV_CONVERT);
+  ms[EV_DIGITS] = span(EV_CONVERT, EV_DIGITS);
+  ms[EV_SORT] = span(EV_DIGITS, EV_SORT);
+  ms[EV_ACC] = span(EV_ACC_S, EV_ACC);
+  ms[EV_REDUCE] = span(EV_RED_S, EV_REDUCE);
   msm_amd_timings& T = ctx->timings;
   const float inv = 1.0f / (float)n_inst;
   T.convert_ms += ms[EV_CONVERT] * inv;
@@ -441,14 +457,7 @@ void accumulate_timings(msm_amd_ctx* ctx, InstanceSlot& s, const Plan& p, float 
   T.sort_ms += ms[EV_SORT] * inv;
   T.accumulate_ms += ms[EV_ACC] * inv;
   T.reduce_ms += ms[EV_REDUCE] * inv;
-  {
-    float t = 0;
-    if (hipEventElapsedTime(&t, s.ev[EV_ACC_K0], s.ev[EV_ACC_K1]) != hipSuccess) {
-      (void)hipGetLastError();
-      t = 0;
-    }
-    T.accumulate_kernel_ms += t * inv;
-  }
+  T.accumulate_kernel_ms += span(EV_ACC_K0, EV_ACC_K1) * inv;
   T.final_ms += final_ms * inv;
   T.total_gpu_ms += (ms[EV_CONVERT] + ms[EV_DIGITS] + ms[EV_SORT] + ms[EV_ACC] + ms[EV_REDUCE]) * inv;
   T.n = p.n;
@@ -477,6 +486,7 @@ int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size
     Workspace& w = ctx->ws[i % (size_t)kWorkspaces];
     int rc = enqueue_msm(ctx, w, ctx->slots[i], scalar_layout, point_layout, d_scalars[i], d_points[i], n[i], &plans[i]);
     if (rc) {
+      (void)hipStreamSynchronize(ctx->front_stream);
       (void)hipStreamSynchronize(ctx->stream);
       (void)hipStreamSynchronize(ctx->reduce_stream);
       return rc;
@@ -492,9 +502,10 @@ int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size
     std::memcpy((uint8_t*)out_host + i * 96, &res, 96);
     accumulate_timings(ctx, s, plans[i], final_ms, n_inst);
   }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->front_stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->reduce_stream));
-  for (int k = 0; k < kWorkspaces; ++k) ctx->ws[k].reduce_pending = false;
+  for (int k = 0; k < kWorkspaces; ++k) ctx->ws[k].reduce_pending = ctx->ws[k].acc_pending = false;
   return MSM_AMD_OK;
 }
 
@@ -580,10 +591,16 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   msm_amd_ctx* ctx = new msm_amd_ctx();
   ctx->device = device;
   if (const char* e = std::getenv("MSM_AMD_OVERLAP_REDUCE")) ctx->overlap_reduce = std::atoi(e) != 0;
-  bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&ctx->reduce_stream, hipStreamNonBlocking) == hipSuccess;
+  if (const char* e = std::getenv("MSM_AMD_OVERLAP_FRONT")) ctx->overlap_front = std::atoi(e) != 0;
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  // the short front-end / reduction kernels get priority over the long accumulate grid
+  bool ok = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_least) == hipSuccess &&
+            hipStreamCreateWithPriority(&ctx->reduce_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+            hipStreamCreateWithPriority(&ctx->front_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   for (int k = 0; ok && k < kWorkspaces; ++k)
-    ok = hipEventCreateWithFlags(&ctx->ws[k].acc_done, hipEventDisableTiming) == hipSuccess &&
+    ok = hipEventCreateWithFlags(&ctx->ws[k].front_done, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ctx->ws[k].acc_done, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&ctx->ws[k].reduce_done, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
@@ -595,6 +612,7 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
     std::fprintf(stderr, "msm_amd: %s\n", ctx->last_error.c_str());
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->reduce_stream);
+    (void)hipStreamDestroy(ctx->front_stream);
     delete ctx;
     return rc;
   }
@@ -628,6 +646,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (ctx == g_global_ctx) g_global_ctx = nullptr;
   }
   (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->front_stream);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->reduce_stream);
   for (int k = 0; k < kWorkspaces; ++k) {
@@ -637,6 +656,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
                          &w.partial, &w.conv_scalars, &w.conv_points, &w.conv_tmp};
     for (DeviceBuf* b : bufs)
       if (b->p) (void)hipFree(b->p);
+    if (w.front_done) (void)hipEventDestroy(w.front_done);
     if (w.acc_done) (void)hipEventDestroy(w.acc_done);
     if (w.reduce_done) (void)hipEventDestroy(w.reduce_done);
   }
@@ -650,6 +670,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   }
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->reduce_stream);
+  (void)hipStreamDestroy(ctx->front_stream);
   delete ctx;
 }
 
@@ -819,6 +840,7 @@ int msm_amd_synchronize(msm_amd_ctx* ctx) {
   if (!ctx) return MSM_AMD_INPUT_ERROR;
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->front_stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->reduce_stream));
   return MSM_AMD_OK;
