@@ -140,6 +140,10 @@ void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, co
                        (const PlanCounters*)b.counters, p.n, p.lb, p.CH, buckets, partials);
   }
   if (after_kernel) (void)hipEventRecord(after_kernel, st);
+}
+
+// Sums the partial results of split buckets (no-op launches when nothing was split).
+void launch_combine(hipStream_t st, const Plan& p, const SortBuffers& b, PtI* buckets, PtI* partials) {
   // multi_list doubles as big_list storage: its second half (entries max_items/2 ..) is free because a split
   // bucket accounts for at least two items
   uint32_t* big_list = b.multi_list + p.max_items / 2 + 1;

@@ -59,6 +59,8 @@ void launch_ark_affine_to_affine(hipStream_t st, const uint8_t* in, uint32_t n, 
 void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
                        PtI* partials, bool low_occupancy, hipEvent_t before_kernel, hipEvent_t after_kernel);
 
+void launch_combine(hipStream_t st, const Plan& p, const SortBuffers& b, PtI* buckets, PtI* partials);
+
 // k_reduce.hip
 int reduce_set_attributes(const char** failed);
 void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, PtI* S, PtI* T, Jacobian* partial);

@@ -392,8 +392,11 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   //   reduce : window reduction + copy of instance i                 -- needs main(i)
   hipStream_t fs = ctx->overlap_front ? ctx->front_stream : st;
   hipStream_t rs = ctx->overlap_reduce ? ctx->reduce_stream : st;
-  if (w.acc_pending && fs != st) {   // the previous accumulate/combine in this workspace still reads its plan
+  if (w.acc_pending && fs != st) {   // the previous accumulate in this workspace still reads its plan ...
     HIP_TRY(ctx, hipStreamWaitEvent(fs, w.acc_done, 0));
+  }
+  if (w.reduce_pending && fs != rs) {   // ... and so does its combine pass on the reduce stream
+    HIP_TRY(ctx, hipStreamWaitEvent(fs, w.reduce_done, 0));
   }
   w.acc_pending = false;
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_START], fs));
@@ -423,8 +426,12 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   HIP_TRY(ctx, hipEventRecord(w.acc_done, st));
   w.acc_pending = true;
 
+  // combine (split buckets) + window reduction + copy: off the main stream, which goes straight to the next
+  // accumulate.  front(i+2) reuses this workspace's plan buffers, which combine still reads: it waits for
+  // reduce_done as well (see the top of this function).
   if (rs != st) HIP_TRY(ctx, hipStreamWaitEvent(rs, w.acc_done, 0));
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_RED_S], rs));
+  launch_combine(rs, p, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p);
   if ((rc = enqueue_reduce(ctx, w, rs, p, (const PtI*)w.buckets.p))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial, w.partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, rs));
