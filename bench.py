@@ -33,7 +33,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # under torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -54,14 +54,14 @@ def main():
         d_sc.append(ds)
     ns = [n] * inst
 
-    gathered = None
+    gatherer = mg.ResultGatherer(dist, dev, inst) if dist is not None else None
 
-    def step():
-        nonlocal gathered
-        outs = cfg.msm_batch_device(d_sc, d_pts, ns)
-        if dist is not None:                             # RCCL gather of per-instance results over xGMI
-            gathered = mg.all_gather_results(outs, dist, dev)
-        return outs
+    def finish(handle):
+        outs = cfg.wait_batch(handle)                    # host Horner pass of the batch
+        if gatherer is not None:                         # RCCL gather of per-instance results over xGMI
+            gatherer.gather(outs)                        # (enqueued; completes before the closing barrier)
+        t = cfg.timings()                                # hipEvent times on the library's own streams
+        return outs, t
 
     def barrier():
         if dist is not None:
@@ -69,22 +69,40 @@ def main():
         torch.cuda.synchronize()
         cfg.synchronize()
 
-    for _ in range(args.warmup):
-        outs = step()
+    def run_steps(k, record):
+        """k steps, software-pipelined: step i+1 is submitted before step i is waited for, so the GPU never
+        idles between steps; every step's results are produced and returned inside the loop."""
+        outs, pending = None, None
+        for _ in range(k):
+            h = cfg.submit_batch_device(d_sc, d_pts, ns)
+            if pending is not None:
+                outs, t = finish(pending)
+                record(t)
+            pending = h
+        if pending is not None:
+            outs, t = finish(pending)
+            record(t)
+        return outs
+
     acc_ms, acc_stage_ms, tot_ms, sort_ms, red_ms, fin_ms = [], [], [], [], [], []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        outs = step()
-        t = cfg.timings()                          # hipEvent times on the library's own stream
+
+    def record(t):
         acc_ms.append(t.accumulate_kernel_ms)
         acc_stage_ms.append(t.accumulate_ms)
         tot_ms.append(t.total_gpu_ms)
         sort_ms.append(t.sort_ms)
         red_ms.append(t.reduce_ms)
         fin_ms.append(t.final_ms)
+
+    outs = run_steps(args.warmup, lambda t: None)
+    barrier()
+    t0 = time.perf_counter()
+    outs = run_steps(args.steps, record)
     barrier()
     elapsed = time.perf_counter() - t0
+    if gatherer is not None:
+        allr = gatherer.fetch()                          # every rank holds every instance's result
+        assert allr[rank * inst:(rank + 1) * inst] == outs, "gathered results differ from the local ones"
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -156,7 +174,8 @@ def main():
             "config": {"workload": f"log_size={args.log_size}, {inst} instances per GPU, h2c BN254 G1 "
                                    f"(gpu_msm_h2c pipeline, window {window})",
                        "instances_per_gpu": inst, "log_size": args.log_size, "window_size": window,
-                       "parallelism": f"instance-sharded x{world}, RCCL all_gather of 96-byte results"},
+                       "parallelism": f"instance-sharded x{world}, RCCL all_gather of 96-byte results",
+                       "pipelining": "step k+1 is submitted before step k's results are collected (submit/wait API)"},
             "stage_ms_per_msm": {"sort": round(sum(sort_ms) / len(sort_ms), 4),
                                  "accumulate": round(sum(acc_stage_ms) / len(acc_stage_ms), 4),
                                  "accumulate_kernel": round(acc_avg_ms, 4),

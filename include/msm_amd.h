@@ -131,6 +131,15 @@ int msm_amd_msm_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layo
                              const void* const* d_scalars, const void* const* d_points, const size_t* n,
                              void* out_host);
 
+/* Pipelined form of msm_amd_msm_batch_device: submit enqueues all GPU work of the batch and returns a ticket;
+ * wait finishes it (host Horner pass) and fills out_host (n_inst x 96 B, must stay valid until then).  Up to 4
+ * batches may be in flight, so the front end of batch k+1 runs under the accumulation of batch k and the host
+ * work of batch k under the GPU work of batch k+1.  The d_scalars / d_points / n arrays are read at submit. */
+int msm_amd_submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
+                                const void* const* d_scalars, const void* const* d_points, const size_t* n,
+                                void* out_host, int* ticket);
+int msm_amd_wait_batch(msm_amd_ctx* ctx, int ticket);
+
 /* ---- device memory helpers (so callers without a HIP binding can stage data) ------------------ */
 int msm_amd_device_alloc(msm_amd_ctx* ctx, size_t bytes, void** d_ptr);
 int msm_amd_device_free(msm_amd_ctx* ctx, void* d_ptr);

@@ -33,7 +33,7 @@ EXPORTS = [
     "msm_amd_last_error", "msm_amd_set_window_size", "msm_amd_auto_window_size", "msm_amd_gpu_msm_h2c",
     "msm_amd_metal_msm_ark", "msm_amd_msm", "msm_amd_msm_batch", "msm_amd_msm_best", "msm_amd_gpu_with_cpu",
     "msm_amd_reference_split", "msm_amd_msm_device",
-    "msm_amd_msm_batch_device", "msm_amd_device_alloc", "msm_amd_device_free", "msm_amd_copy_to_device",
+    "msm_amd_msm_batch_device", "msm_amd_submit_batch_device", "msm_amd_wait_batch", "msm_amd_device_alloc", "msm_amd_device_free", "msm_amd_copy_to_device",
     "msm_amd_copy_to_host", "msm_amd_stream", "msm_amd_synchronize", "msm_amd_generate_instance",
     "msm_amd_prepare_buckets_indices", "msm_amd_sort_buckets_indices", "msm_amd_bucket_wise_accumulation",
     "msm_amd_sum_reduction", "msm_amd_final_accumulation", "msm_amd_test_op", "msm_amd_test_op_host",
@@ -91,6 +91,9 @@ def _lib():
         L.msm_amd_msm_device.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
         L.msm_amd_msm_batch_device.argtypes = [c_void_p, c_int, c_int, c_size_t, POINTER(c_void_p),
                                                POINTER(c_void_p), POINTER(c_size_t), c_void_p]
+        L.msm_amd_submit_batch_device.argtypes = [c_void_p, c_int, c_int, c_size_t, POINTER(c_void_p),
+                                                  POINTER(c_void_p), POINTER(c_size_t), c_void_p, POINTER(c_int)]
+        L.msm_amd_wait_batch.argtypes = [c_void_p, c_int]
         L.msm_amd_device_alloc.argtypes = [c_void_p, c_size_t, POINTER(c_void_p)]
         L.msm_amd_device_free.argtypes = [c_void_p, c_void_p]
         L.msm_amd_copy_to_device.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
@@ -180,6 +183,24 @@ class MsmConfig:
         nn = (c_size_t * k)(*ns)
         out = ctypes.create_string_buffer(96 * k)
         self._check(_lib().msm_amd_msm_batch_device(self.h, scalar_layout, point_layout, k, sp, pp, nn, out))
+        return [out.raw[96 * i:96 * i + 96] for i in range(k)]
+
+    def submit_batch_device(self, d_scalars, d_points, ns, scalar_layout=SCALAR_MONT_LE,
+                            point_layout=POINT_H2C_AFFINE):
+        """Enqueue a batch; returns a handle for wait_batch (pipelined form of msm_batch_device)."""
+        k = len(ns)
+        sp = (c_void_p * k)(*d_scalars)
+        pp = (c_void_p * k)(*d_points)
+        nn = (c_size_t * k)(*ns)
+        out = ctypes.create_string_buffer(96 * k)
+        ticket = c_int(-1)
+        self._check(_lib().msm_amd_submit_batch_device(self.h, scalar_layout, point_layout, k, sp, pp, nn, out,
+                                                       ctypes.byref(ticket)))
+        return (ticket.value, out, k)
+
+    def wait_batch(self, handle):
+        ticket, out, k = handle
+        self._check(_lib().msm_amd_wait_batch(self.h, ticket))
         return [out.raw[96 * i:96 * i + 96] for i in range(k)]
 
     # ---- device memory ---------------------------------------------------------------------

@@ -2,7 +2,7 @@
 // arguments and the same two report lines:
 //
 //   gpu_profiler [log_size=16] [num_instances=1] [mode=gpu] [retries=3] [parallel=false]
-//                [--seed S] [--device D] [--window C] [--json]
+//                [--seed S] [--device D] [--window C] [--layout h2c|ark] [--json]
 //
 // Modes (gpu_profiler.rs:143-172)
 //   gpu       metal::msm::gpu_msm_h2c      -> msm_amd_gpu_msm_h2c (host buffers, upload included)
@@ -38,11 +38,13 @@ int main(int argc, char** argv) {
   uint64_t seed = 0xB2540000ull;
   int device = -1, window = 0;
   bool json = false;
+  bool ark = false;   // --layout ark: ark_bn254 G1Projective points (96 B, z = one), config 5 of BASELINE.json
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 0);
     else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
     else if (a == "--window" && i + 1 < argc) window = std::atoi(argv[++i]);
+    else if (a == "--layout" && i + 1 < argc) ark = std::string(argv[++i]) == "ark";
     else if (a == "--json") json = true;
     else pos.push_back(a);
   }
@@ -92,6 +94,27 @@ int main(int argc, char** argv) {
       if ((st = msm_amd_copy_to_host(ctx, h_sc[j].data(), d_sc[j], n * 32))) die(ctx, st, "copy_to_host");
     }
   }
+  if (ark) {
+    if (mode != "gpu_resident") {
+      std::fprintf(stderr, "[ERROR] --layout ark is measured in gpu_resident mode only\n");
+      return 1;
+    }
+    // build G1Projective {x, y, z = R mod p} on the host from the generated affine points and keep it resident
+    static const uint8_t kMontOne[32] = {0x9d, 0x0d, 0x8f, 0xc5, 0x8d, 0x43, 0x5d, 0xd3, 0x3d, 0x0b, 0xc7,
+                                         0xf5, 0x28, 0xeb, 0x78, 0x0a, 0x2c, 0x46, 0x79, 0x78, 0x6f, 0xa3,
+                                         0x6e, 0x66, 0x2f, 0xdf, 0x07, 0x9a, 0xc1, 0x77, 0x0a, 0x0e};
+    std::vector<uint8_t> aff(n * 64), proj(n * 96);
+    for (unsigned j = 0; j < num_instances; ++j) {
+      if ((st = msm_amd_copy_to_host(ctx, aff.data(), d_pts[j], n * 64))) die(ctx, st, "copy_to_host");
+      for (size_t i = 0; i < n; ++i) {
+        std::memcpy(&proj[i * 96], &aff[i * 64], 64);
+        std::memcpy(&proj[i * 96 + 64], kMontOne, 32);
+      }
+      msm_amd_device_free(ctx, d_pts[j]);
+      if ((st = msm_amd_device_alloc(ctx, n * 96, &d_pts[j]))) die(ctx, st, "device_alloc");
+      if ((st = msm_amd_copy_to_device(ctx, d_pts[j], proj.data(), n * 96))) die(ctx, st, "copy_to_device");
+    }
+  }
   std::vector<uint8_t> out((size_t)num_instances * 96);
   std::vector<const void*> sp(num_instances), pp(num_instances);
   std::vector<size_t> ns(num_instances, n);
@@ -132,8 +155,9 @@ int main(int argc, char** argv) {
       }
     } else {
       for (unsigned j = 0; j < num_instances; ++j) { sp[j] = d_sc[j]; pp[j] = d_pts[j]; }
-      st = msm_amd_msm_batch_device(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, num_instances, sp.data(),
-                                    pp.data(), ns.data(), out.data());
+      st = msm_amd_msm_batch_device(ctx, MSM_AMD_SCALAR_MONT_LE,
+                                    ark ? MSM_AMD_POINT_ARK_PROJECTIVE : MSM_AMD_POINT_H2C_AFFINE, num_instances,
+                                    sp.data(), pp.data(), ns.data(), out.data());
       if (st) die(ctx, st, "msm_batch_device");
     }
   }

@@ -62,6 +62,15 @@ struct Workspace {
 };
 
 constexpr int kWorkspaces = 2;
+constexpr int kMaxBatches = 4;   // batches that may be in flight between submit and wait
+
+struct Batch {
+  std::vector<InstanceSlot> slots;
+  std::vector<Plan> plans;
+  void* out = nullptr;
+  size_t n_inst = 0;
+  bool active = false;
+};
 
 struct msm_amd_ctx {
   int device = 0;
@@ -74,8 +83,9 @@ struct msm_amd_ctx {
   std::mutex mu;
   std::string last_error;
   uint32_t forced_window = 0;
+  int next_ws = 0;
   DeviceBuf scratch_a, scratch_b, scratch_c;
-  std::vector<InstanceSlot> slots;
+  Batch batches[kMaxBatches];
   msm_amd_timings timings{};
 };
 
@@ -473,25 +483,37 @@ void accumulate_timings(msm_amd_ctx* ctx, InstanceSlot& s, const Plan& p, float 
   T.reserved = (uint32_t)n_inst;
 }
 
-// Batch of MSMs with device-resident inputs: enqueue everything, then finish each instance on the host as
-// soon as its partials have landed (the host Horner of instance i overlaps the GPU work of i+1..).
-int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
-                     const void* const* d_scalars, const void* const* d_points, const size_t* n, void* out_host) {
-  if (!ctx || !d_scalars || !d_points || !n || !out_host || n_inst == 0)
+// Batch of MSMs with device-resident inputs, in two halves so that callers can pipeline batches:
+//   submit_batch_device  enqueues every kernel of every instance (three streams, see enqueue_msm) and returns
+//   wait_batch           finishes each instance on the host as soon as its partial points have landed (the host
+//                        Horner pass of instance i overlaps the GPU work of i+1.. and of later batches)
+int submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
+                        const void* const* d_scalars, const void* const* d_points, const size_t* n, void* out_host,
+                        int* ticket) {
+  if (!ctx || !d_scalars || !d_points || !n || !out_host || !ticket || n_inst == 0)
     return fail(ctx, MSM_AMD_INPUT_ERROR, "null argument or empty batch");
   if (point_bytes(point_layout) == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown point layout");
   for (size_t i = 0; i < n_inst; ++i) {
     if (n[i] == 0 || n[i] > 0x7FFFFFFFull || !d_scalars[i] || !d_points[i])
       return fail(ctx, MSM_AMD_INPUT_ERROR, "instance with n == 0, n >= 2^31 or null pointer");
   }
+  int id = -1;
+  for (int b = 0; b < kMaxBatches; ++b)
+    if (!ctx->batches[b].active) {
+      id = b;
+      break;
+    }
+  if (id < 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "too many batches in flight: wait for one first");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (ctx->slots.size() < n_inst) ctx->slots.resize(n_inst);
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // inputs staged on stream 0 (uploads, generator) are complete
-  std::vector<Plan> plans(n_inst);
-  ctx->timings = msm_amd_timings{};
+  Batch& B = ctx->batches[id];
+  if (B.slots.size() < n_inst) B.slots.resize(n_inst);
+  B.plans.assign(n_inst, Plan{});
+  B.out = out_host;
+  B.n_inst = n_inst;
   for (size_t i = 0; i < n_inst; ++i) {
-    Workspace& w = ctx->ws[i % (size_t)kWorkspaces];
-    int rc = enqueue_msm(ctx, w, ctx->slots[i], scalar_layout, point_layout, d_scalars[i], d_points[i], n[i], &plans[i]);
+    Workspace& w = ctx->ws[ctx->next_ws];
+    ctx->next_ws = (ctx->next_ws + 1) % kWorkspaces;
+    int rc = enqueue_msm(ctx, w, B.slots[i], scalar_layout, point_layout, d_scalars[i], d_points[i], n[i], &B.plans[i]);
     if (rc) {
       (void)hipStreamSynchronize(ctx->front_stream);
       (void)hipStreamSynchronize(ctx->stream);
@@ -499,21 +521,37 @@ int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size
       return rc;
     }
   }
-  for (size_t i = 0; i < n_inst; ++i) {
-    InstanceSlot& s = ctx->slots[i];
+  B.active = true;
+  *ticket = id;
+  return MSM_AMD_OK;
+}
+
+int wait_batch(msm_amd_ctx* ctx, int ticket) {
+  if (!ctx || ticket < 0 || ticket >= kMaxBatches || !ctx->batches[ticket].active)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown batch ticket");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Batch& B = ctx->batches[ticket];
+  ctx->timings = msm_amd_timings{};
+  for (size_t i = 0; i < B.n_inst; ++i) {
+    InstanceSlot& s = B.slots[i];
     HIP_TRY(ctx, hipEventSynchronize(s.ev[EV_REDUCE]));
     const auto t0 = std::chrono::steady_clock::now();
-    const Jacobian res = normalise(host_combine(s.h_partial, plans[i]));
+    const Jacobian res = normalise(host_combine(s.h_partial, B.plans[i]));
     const float final_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    std::memcpy((uint8_t*)out_host + i * 96, &res, 96);
-    accumulate_timings(ctx, s, plans[i], final_ms, n_inst);
+    std::memcpy((uint8_t*)B.out + i * 96, &res, 96);
+    accumulate_timings(ctx, s, B.plans[i], final_ms, B.n_inst);
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->front_stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->reduce_stream));
-  for (int k = 0; k < kWorkspaces; ++k) ctx->ws[k].reduce_pending = ctx->ws[k].acc_pending = false;
+  B.active = false;
   return MSM_AMD_OK;
+}
+
+int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
+                     const void* const* d_scalars, const void* const* d_points, const size_t* n, void* out_host) {
+  int ticket = -1;
+  int rc = submit_batch_device(ctx, scalar_layout, point_layout, n_inst, d_scalars, d_points, n, out_host, &ticket);
+  if (rc) return rc;
+  return wait_batch(ctx, ticket);
 }
 
 // Host-buffer variant: stage inputs into device scratch, then run the device path per instance.
@@ -529,9 +567,11 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
     int rc;
     if ((rc = ensure(ctx, ctx->scratch_b, n[i] * scalar_bytes(scalar_layout)))) return rc;
     if ((rc = ensure(ctx, ctx->scratch_c, n[i] * pb))) return rc;
+    // uploads go on the stream the front end runs on, so conversion / digits see them in order
+    hipStream_t up = ctx->overlap_front ? ctx->front_stream : ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars[i], n[i] * scalar_bytes(scalar_layout),
-                                hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, points[i], n[i] * pb, hipMemcpyHostToDevice, ctx->stream));
+                                hipMemcpyHostToDevice, up));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, points[i], n[i] * pb, hipMemcpyHostToDevice, up));
     const void* ds = ctx->scratch_b.p;
     const void* dp = ctx->scratch_c.p;
     msm_amd_timings keep = ctx->timings;
@@ -670,7 +710,8 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   DeviceBuf* sbufs[] = {&ctx->scratch_a, &ctx->scratch_b, &ctx->scratch_c};
   for (DeviceBuf* b : sbufs)
     if (b->p) (void)hipFree(b->p);
-  for (InstanceSlot& s : ctx->slots) {
+  for (Batch& B : ctx->batches)
+  for (InstanceSlot& s : B.slots) {
     if (s.has_events)
       for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(s.ev[i]);
     if (s.h_partial) (void)hipHostFree(s.h_partial);
@@ -799,6 +840,20 @@ int msm_amd_msm_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layo
   if (!ctx) return MSM_AMD_INPUT_ERROR;
   std::lock_guard<std::mutex> g(ctx->mu);
   return run_batch_device(ctx, scalar_layout, point_layout, n_inst, d_scalars, d_points, n, out_host);
+}
+
+int msm_amd_submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
+                                const void* const* d_scalars, const void* const* d_points, const size_t* n,
+                                void* out_host, int* ticket) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  return submit_batch_device(ctx, scalar_layout, point_layout, n_inst, d_scalars, d_points, n, out_host, ticket);
+}
+
+int msm_amd_wait_batch(msm_amd_ctx* ctx, int ticket) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  return wait_batch(ctx, ticket);
 }
 
 int msm_amd_msm_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const void* d_scalars,

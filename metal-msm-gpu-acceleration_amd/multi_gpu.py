@@ -29,7 +29,7 @@ def all_gather_results(local_results, dist=None, device=None):
     blob = b"".join(local_results)
     if len(blob) != RESULT_BYTES * len(local_results):
         raise ValueError("every result must be 96 bytes")
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None:
         return list(local_results)
     import torch
     mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
@@ -40,3 +40,37 @@ def all_gather_results(local_results, dist=None, device=None):
     dist.all_gather_into_tensor(out, mine)
     raw = bytes(out.cpu().numpy().tobytes())
     return [raw[i * RESULT_BYTES:(i + 1) * RESULT_BYTES] for i in range(world * len(local_results))]
+
+
+class ResultGatherer:
+    """Per-step all-gather of the 96-byte results without a host synchronisation inside the step: staging and
+    device tensors are allocated once, the copy to the device is asynchronous from pinned memory, the collective
+    is enqueued on the backend's stream, and `fetch()` (one device->host copy) is only called when the caller
+    wants to look at the gathered bytes."""
+
+    def __init__(self, dist, device, per_rank):
+        import torch
+        self.dist, self.device, self.per_rank = dist, device, per_rank
+        self.world = dist.get_world_size() if dist is not None else 1
+        nbytes = RESULT_BYTES * per_rank
+        pin = device is not None and getattr(device, "type", "cpu") == "cuda"
+        self.stage = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pin)
+        dev = device if device is not None else torch.device("cpu")
+        self.mine = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.all = torch.empty(self.world * nbytes, dtype=torch.uint8, device=dev)
+
+    def gather(self, local_results):
+        blob = b"".join(local_results)
+        if len(blob) != RESULT_BYTES * self.per_rank:
+            raise ValueError("expected %d results of 96 bytes" % self.per_rank)
+        import torch
+        self.stage.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        self.mine.copy_(self.stage, non_blocking=True)
+        if self.dist is not None:
+            self.dist.all_gather_into_tensor(self.all, self.mine)
+        else:
+            self.all.copy_(self.mine)
+
+    def fetch(self):
+        raw = bytes(self.all.cpu().numpy().tobytes())
+        return [raw[i * RESULT_BYTES:(i + 1) * RESULT_BYTES] for i in range(self.world * self.per_rank)]

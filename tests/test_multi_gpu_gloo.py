@@ -32,6 +32,9 @@ def _worker(rank, world, port, per_rank, n, q):
         pts, sc = co.gen_instance(mg.instance_seed(g), n, True, threads=1)
         local.append(co.msm_best(sc, pts, n, 1))
     allr = mg.all_gather_results(local, dist)
+    g = mg.ResultGatherer(dist, None, per_rank)        # the preallocated form bench.py uses
+    g.gather(local)
+    assert g.fetch() == allr
     q.put((rank, allr))
     dist.barrier()
     dist.destroy_process_group()
