@@ -1,5 +1,7 @@
 // Sort-stage kernels: digit extraction, per-window two-pass LDS counting sort, work-item planning.
 // See device_common.hip.h for the pipeline overview.
+#include <algorithm>
+
 #include "device_common.hip.h"
 #include "launch.h"
 
@@ -235,11 +237,11 @@ plan_kernel(const uint32_t* __restrict__ bucket_size, uint32_t lb, uint32_t CH,
 // chunk of a large bucket).  Lanes of a wave finish together only if their items have the same length,
 // and the longest items must start first, so items are counting-sorted by DESCENDING size
 // (CH + 1 size classes).  Three small kernels over the buckets:
-//   size_hist_kernel     LDS histogram of item sizes per workgroup -> global size_bins
-//   size_scan_kernel     one workgroup: descending exclusive scan of size_bins (-> cursors), exclusive
-//                        scan of win_items (-> window base of item ids), total item count
-//   size_scatter_kernel  every bucket reserves its positions: one LDS-aggregated global atomic per
-//                        (workgroup, size class), LDS atomics inside the workgroup
+//   size_hist_kernel     LDS histogram of item sizes per workgroup -> one column of a (size class x workgroup) table
+//   size_scan_kernel     one workgroup: exclusive scan of the table in (descending size, workgroup) order,
+//                        exclusive scan of win_items (-> window base of item ids), total item count
+//   size_scatter_kernel  every bucket takes its positions with LDS atomics relative to its workgroup's bases;
+//                        no global atomics except one per workgroup for the list of split buckets
 constexpr int kSizeThreads = 1024;
 
 __device__ __forceinline__ void bucket_items(uint32_t s, uint32_t CH, uint32_t* nfull, uint32_t* last) {
@@ -250,7 +252,7 @@ __device__ __forceinline__ void bucket_items(uint32_t s, uint32_t CH, uint32_t* 
 
 __global__ void __launch_bounds__(kSizeThreads)
 size_hist_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_buckets, uint32_t CH,
-                 uint32_t* __restrict__ size_bins) {
+                 uint32_t* __restrict__ wg_bins /* [CH + 1 rows, row r = size class CH - r][gridDim.x] */) {
   extern __shared__ uint32_t lds_u32[];
   for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x) lds_u32[i] = 0;
   __syncthreads();
@@ -262,23 +264,32 @@ size_hist_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_bucket
     if (last) atomicAdd(&lds_u32[last], 1u);
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x) {
-    const uint32_t v = lds_u32[i];
-    if (v) atomicAdd(&size_bins[i], v);
-  }
+  // no global atomics: every workgroup owns one column of the table
+  for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x)
+    wg_bins[(size_t)(CH - i) * gridDim.x + blockIdx.x] = lds_u32[i];
 }
 
-// One workgroup of 1024 threads.  CH <= 1024, W <= 1024.
+// One workgroup of 1024 threads: exclusive scan of the flattened (descending size class, workgroup) table ->
+// first order[] position of every (size class, workgroup); exclusive scan of win_items -> window bases.
 __global__ void __launch_bounds__(1024)
-size_scan_kernel(uint32_t* __restrict__ size_bins, uint32_t CH, uint32_t* __restrict__ win_items, uint32_t W,
+size_scan_kernel(uint32_t* __restrict__ wg_bins, uint32_t table_len, uint32_t* __restrict__ win_items, uint32_t W,
                  PlanCounters* __restrict__ counters) {
   __shared__ uint32_t scratch[17];
-  // descending order: thread t owns size class CH - t
   const uint32_t t = threadIdx.x;
-  uint32_t v = (t <= CH) ? size_bins[CH - t] : 0u;
+  const uint32_t per = (table_len + blockDim.x - 1) / blockDim.x;
+  const uint32_t first = t * per;
+  uint32_t local = 0;
+  for (uint32_t k = 0; k < per; ++k)
+    if (first + k < table_len) local += wg_bins[first + k];
   uint32_t total;
-  uint32_t ex = block_exclusive_scan(v, scratch, &total);
-  if (t <= CH) size_bins[CH - t] = ex;
+  uint32_t run = block_exclusive_scan(local, scratch, &total);
+  for (uint32_t k = 0; k < per; ++k) {
+    if (first + k < table_len) {
+      const uint32_t v = wg_bins[first + k];
+      wg_bins[first + k] = run;
+      run += v;
+    }
+  }
   if (t == 0) {
     counters->total_items = total;
     counters->multi_count = 0;
@@ -292,28 +303,23 @@ size_scan_kernel(uint32_t* __restrict__ size_bins, uint32_t CH, uint32_t* __rest
 
 __global__ void __launch_bounds__(kSizeThreads)
 size_scatter_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_buckets, uint32_t CH,
-                    uint32_t* __restrict__ size_cursor, uint2* __restrict__ order,
+                    const uint32_t* __restrict__ wg_base, uint2* __restrict__ order,
                     uint32_t* __restrict__ multi_list, PlanCounters* __restrict__ counters) {
   extern __shared__ uint32_t lds_u32[];
-  uint32_t* cnt = lds_u32;              // [CH + 1] local counts, then local ranks
-  uint32_t* base = lds_u32 + CH + 1;    // [CH + 1] reserved global base per size class
-  for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x) cnt[i] = 0;
+  uint32_t* cnt = lds_u32;              // [CH + 1] local ranks
+  uint32_t* base = lds_u32 + CH + 1;    // [CH + 1] first position of this workgroup per size class
+  uint32_t* multi = lds_u32 + 2 * (CH + 1);   // [2]: local count of split buckets, reserved global base
+  for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x) {
+    cnt[i] = 0;
+    base[i] = wg_base[(size_t)(CH - i) * gridDim.x + blockIdx.x];
+  }
+  if (threadIdx.x == 0) multi[0] = 0;
   __syncthreads();
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t nfull = 0, last = 0;
+  uint32_t nfull = 0, last = 0, mslot = 0;
+  bool split = false;
   if (b < total_buckets) {
     bucket_items(bucket_size[b], CH, &nfull, &last);
-    if (nfull) atomicAdd(&cnt[CH], nfull);
-    if (last) atomicAdd(&cnt[last], 1u);
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x) {
-    const uint32_t v = cnt[i];
-    base[i] = v ? atomicAdd(&size_cursor[i], v) : 0u;
-    cnt[i] = 0;
-  }
-  __syncthreads();
-  if (b < total_buckets) {
     if (nfull) {
       const uint32_t pos = base[CH] + atomicAdd(&cnt[CH], nfull);
       for (uint32_t j = 0; j < nfull; ++j) order[pos + j] = make_uint2(b, j);
@@ -322,11 +328,13 @@ size_scatter_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_buc
       const uint32_t pos = base[last] + atomicAdd(&cnt[last], 1u);
       order[pos] = make_uint2(b, nfull);
     }
-    if (nfull + (last ? 1u : 0u) > 1u) {
-      const uint32_t slot = atomicAdd(&counters->multi_count, 1u);
-      multi_list[slot] = b;
-    }
+    split = nfull + (last ? 1u : 0u) > 1u;
+    if (split) mslot = atomicAdd(&multi[0], 1u);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) multi[1] = multi[0] ? atomicAdd(&counters->multi_count, multi[0]) : 0u;   // one per workgroup
+  __syncthreads();
+  if (split) multi_list[multi[1] + mslot] = b;
 }
 
 // ark_bn254::G1Affine {x: Fq, y: Fq, infinity: bool} = 72 bytes (8-byte aligned).
@@ -385,24 +393,25 @@ void launch_digits(hipStream_t st, const Plan& p, const u256* scalars, int scala
 
 void launch_sort(hipStream_t st, const Plan& p, const SortBuffers& b) {
   const uint32_t nhi = 1u << p.hb, nfine = 1u << p.fb;
-  hipLaunchKernelGGL(coarse_hist_kernel, dim3(p.Q, p.W), dim3(kSortThreads), nhi * 4, st,
+  hipLaunchKernelGGL(coarse_hist_kernel, dim3(p.Q, p.W), dim3(p.front_threads), nhi * 4, st,
                      (const uint16_t*)b.digits, p.n, p.fb, nhi, p.chunk, b.coarse_cnt);
   hipLaunchKernelGGL(coarse_prefix_kernel, dim3(p.W), dim3(1024), 0, st, b.coarse_cnt, p.Q, nhi, b.region_start);
-  hipLaunchKernelGGL(coarse_scatter_kernel, dim3(p.Q, p.W), dim3(kSortThreads), nhi * 4, st,
+  hipLaunchKernelGGL(coarse_scatter_kernel, dim3(p.Q, p.W), dim3(p.front_threads), nhi * 4, st,
                      (const uint16_t*)b.digits, p.n, p.hb, p.fb, p.chunk, (const uint32_t*)b.coarse_cnt, b.tmp_idx,
                      b.tmp_fine);
-  hipLaunchKernelGGL(fine_sort_kernel, dim3(nhi, p.W), dim3(kSortThreads), (kFineCap + nfine + 32) * 4, st,
+  hipLaunchKernelGGL(fine_sort_kernel, dim3(nhi, p.W), dim3(std::max(p.front_threads, nfine)), (kFineCap + nfine + 32) * 4, st,
                      (const uint32_t*)b.tmp_idx, (const uint16_t*)b.tmp_fine, p.n, p.lb, p.fb,
                      (const uint32_t*)b.region_start, b.sorted, b.bucket_size);
-  hipLaunchKernelGGL(plan_kernel, dim3(p.W), dim3(kSortThreads), lds_plan_bytes(p.lb), st,
+  hipLaunchKernelGGL(plan_kernel, dim3(p.W), dim3(p.front_threads), lds_plan_bytes(p.lb), st,
                      (const uint32_t*)b.bucket_size, p.lb, p.CH, b.bucket_start, b.item_start, b.win_items);
-  (void)hipMemsetAsync(b.size_bins, 0, (p.CH + 1) * sizeof(uint32_t), st);
-  const unsigned gb = (unsigned)((p.total_buckets + kSizeThreads - 1) / kSizeThreads);
-  hipLaunchKernelGGL(size_hist_kernel, dim3(gb), dim3(kSizeThreads), (p.CH + 1) * 4, st,
+  const unsigned size_threads = p.front_threads;
+  const unsigned gb = (unsigned)((p.total_buckets + size_threads - 1) / size_threads);
+  hipLaunchKernelGGL(size_hist_kernel, dim3(gb), dim3(size_threads), (p.CH + 1) * 4, st,
                      (const uint32_t*)b.bucket_size, (uint32_t)p.total_buckets, p.CH, b.size_bins);
-  hipLaunchKernelGGL(size_scan_kernel, dim3(1), dim3(1024), 0, st, b.size_bins, p.CH, b.win_items, p.W, b.counters);
-  hipLaunchKernelGGL(size_scatter_kernel, dim3(gb), dim3(kSizeThreads), 2 * (p.CH + 1) * 4, st,
-                     (const uint32_t*)b.bucket_size, (uint32_t)p.total_buckets, p.CH, b.size_bins, b.order,
+  hipLaunchKernelGGL(size_scan_kernel, dim3(1), dim3(1024), 0, st, b.size_bins, (p.CH + 1) * gb, b.win_items, p.W,
+                     b.counters);
+  hipLaunchKernelGGL(size_scatter_kernel, dim3(gb), dim3(size_threads), (2 * (p.CH + 1) + 2) * 4, st,
+                     (const uint32_t*)b.bucket_size, (uint32_t)p.total_buckets, p.CH, (const uint32_t*)b.size_bins, b.order,
                      b.multi_list, b.counters);
 }
 

@@ -18,6 +18,7 @@ struct Plan {
   uint32_t lb, nb;            // bucket slots per window nb = 2^lb = max(2^(c-1), 8); slot i holds |digit| = i + 1
   uint32_t Q, chunk;          // sort: chunks per window, points per chunk
   uint32_t hb, fb;            // sort: coarse / fine bits of the slot (hb + fb = lb)
+  uint32_t front_threads;     // workgroup size of the sort / planning kernels (256..1024)
   uint32_t CH;                // accumulate: max points per work item (bucket chunk)
   uint32_t nseg, K;           // reduce: segments per window, bits of segment index (lb - 3)
   uint32_t tree_threads;
@@ -41,7 +42,7 @@ struct SortBuffers {
   uint32_t* bucket_start;     // [W][nb]   offset inside the window's slice of `sorted`
   uint32_t* item_start;       // [W][nb]   first item id of the bucket inside its window
   uint32_t* win_items;        // [W]       items per window, then exclusive prefix (window base)
-  uint32_t* size_bins;        // [CH + 1]  item-size histogram, then write cursors
+  uint32_t* size_bins;        // [CH + 1][ceil(total_buckets / front_threads)] item-size counts, then positions
   uint32_t* sorted;           // [W][n]
   uint2* order;               // [max_items] (bucket, chunk) by descending size
   uint32_t* multi_list;       // [max_items] buckets with more than one item

@@ -61,7 +61,7 @@ struct Workspace {
   bool acc_pending = false, reduce_pending = false;
 };
 
-constexpr int kWorkspaces = 2;
+constexpr int kWorkspaces = 3;
 constexpr int kMaxBatches = 4;   // batches that may be in flight between submit and wait
 
 struct Batch {
@@ -142,8 +142,15 @@ Plan make_plan(size_t n, uint32_t c) {
   p.W = kModulusBits / c + 1;         // signed digits: the top window absorbs the last carry (= ceil(255 / c))
   p.lb = std::max(c - 1, (uint32_t)kSegLog);
   p.nb = 1u << p.lb;                  // slot i <-> digit magnitude i + 1 (c = 3 is padded to 8 slots)
-  // sort pass 1: one 1024-thread workgroup per (chunk, window), about two per CU
-  uint32_t Q = std::max(1u, 512u / p.W);
+  // sort / planning workgroup size: big workgroups are the fastest alone, but they can hardly be placed while
+  // an accumulate grid of another instance is resident (they need 16 free wave slots on one CU at once)
+  p.front_threads = 1024;
+  if (const char* e = std::getenv("MSM_AMD_FRONT_THREADS")) {
+    const int v = std::atoi(e);
+    if (v == 256 || v == 512 || v == 1024) p.front_threads = (uint32_t)v;
+  }
+  // sort pass 1: one workgroup per (chunk, window); about 2 x 1024 threads per CU in total
+  uint32_t Q = std::max(1u, (512u * (1024u / p.front_threads)) / p.W);
   const uint32_t max_q = (uint32_t)((n + 4095) / 4096);
   Q = std::max(1u, std::min(Q, max_q));
   p.Q = Q;
@@ -372,7 +379,8 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   if ((rc = ensure(ctx, w.bstart, p.total_buckets * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.istart, p.total_buckets * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.win_items, 1024 * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, w.size_bins, 1025 * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.size_bins, (size_t)(p.CH + 1) * ((p.total_buckets + p.front_threads - 1) / p.front_threads) *
+                                         sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.sorted, (size_t)p.W * n * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.order, p.max_items * sizeof(uint2)))) return rc;
   if ((rc = ensure(ctx, w.multi_list, p.max_items * sizeof(uint32_t)))) return rc;
