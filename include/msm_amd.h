@@ -33,7 +33,11 @@ enum {
   MSM_AMD_LIBRARY_ERROR = 2,    /* MetalError::LibraryError   (code object missing / not gfx950) */
   MSM_AMD_FUNCTION_ERROR = 3,   /* MetalError::FunctionError  (kernel attribute / symbol) */
   MSM_AMD_PIPELINE_ERROR = 4,   /* MetalError::PipelineError  (launch / runtime failure) */
-  MSM_AMD_INPUT_ERROR = 5       /* MetalError::InputError     (null, n == 0, bad layout/size) */
+  MSM_AMD_INPUT_ERROR = 5,      /* MetalError::InputError     (null, n == 0, bad layout/size) */
+  /* 6..8 mirror HarnessError of the instance-file harness (src/utils/preprocess.rs:11-21). */
+  MSM_AMD_FILE_OPEN_ERROR = 6,        /* HarnessError::FileOpenError        (open/read/write failed) */
+  MSM_AMD_DESERIALIZATION_ERROR = 7,  /* HarnessError::DeserializationError (truncated or malformed bincode) */
+  MSM_AMD_INVALID_DATA = 8            /* HarnessError::InvalidData          (instance count / size mismatch) */
 };
 
 /* Scalar layouts (32 bytes each). */
@@ -154,6 +158,38 @@ int msm_amd_synchronize(msm_amd_ctx* ctx);
 int msm_amd_generate_instance(msm_amd_ctx* ctx, uint64_t seed, size_t n, int scalars_mont, void* d_points,
                               void* d_scalars);
 
+/* ---- instance files (src/utils/preprocess.rs:30-111, 143-212) -------------------------------------
+ * The reference caches benchmark inputs as bincode 1.3 `Vec<(Vec<Vec<u32>>, Vec<Vec<u32>>)>`:
+ *   u64 n_instances; per instance { u64 n_points; n_points x { u64 24; u32 x 24 };
+ *                                   u64 n_scalars; n_scalars x { u64 8; u32 x 8 } }     (all little-endian)
+ * with points in MSM_AMD_POINT_JAC_BE32 and scalars in MSM_AMD_SCALAR_CANON_BE32, under the name
+ * msm_{log_size}x{num_instances}.bin.  These host-only functions read and write that format, so that
+ * files interchange with the reference's ~/.msm_gpu_acceleration/msm_vecs cache.  No ctx and no GPU needed. */
+typedef struct msm_amd_instance_file msm_amd_instance_file;
+
+/* save_msm_instances (preprocess.rs:84-97): points[j] = n[j] x 96 B (JAC_BE32), scalars[j] = n[j] x 32 B
+ * (CANON_BE32). */
+int msm_amd_instances_save(const char* path, size_t n_inst, const size_t* n, const void* const* points,
+                           const void* const* scalars);
+/* load_msm_instances (preprocess.rs:99-111), streaming: open scans the record structure only. */
+int msm_amd_instances_open(const char* path, msm_amd_instance_file** out);
+size_t msm_amd_instances_count(const msm_amd_instance_file* f);
+size_t msm_amd_instances_size(const msm_amd_instance_file* f, size_t j);   /* points (= scalars) of instance j */
+int msm_amd_instances_read(msm_amd_instance_file* f, size_t j, void* points_out, void* scalars_out);
+void msm_amd_instances_close(msm_amd_instance_file* f);
+/* msm_{log}x{n}.bin under dir, or under $HOME/.msm_gpu_acceleration/msm_vecs when dir is NULL
+ * (preprocess.rs:165, 204-212).  Returns the length written (without the NUL), 0 if buf is too small. */
+size_t msm_amd_instances_default_path(const char* dir, uint32_t log_size, uint32_t num_instances, char* buf,
+                                      size_t buf_len);
+/* Host layout conversion between a caller layout and the wire layout (role of the ToLimbs / FromLimbs
+ * impls, limbs_conversion.rs:87-195, 282-389).  to_wire accepts every scalar and point layout; an affine
+ * identity becomes z = 0.  from_wire produces MSM_AMD_SCALAR_{MONT_LE,CANON_LE} and
+ * MSM_AMD_POINT_ARK_PROJECTIVE (a limb reorder: coordinates are not normalised). */
+int msm_amd_to_wire(int scalar_layout, int point_layout, const void* scalars, const void* points, size_t n,
+                    void* scalars_be32_out, void* points_be32_out);
+int msm_amd_from_wire(int scalar_layout, int point_layout, const void* scalars_be32, const void* points_be32,
+                      size_t n, void* scalars_out, void* points_out);
+
 /* ---- per-stage entry points in the reference's wire layout (host buffers) ---------------------
  * These are the `pub` stage functions the reference's own stage tests drive through
  * create_test_instance (sort_buckets.rs:38-69, bucket_wise_accumulation.rs:154-224,
@@ -164,6 +200,11 @@ int msm_amd_prepare_buckets_indices(msm_amd_ctx* ctx, const uint32_t* scalars_be
                                     uint32_t num_windows, uint32_t* pairs_out);
 /* sort_buckets_indices (sort_buckets.rs:15-34): sort n_pairs (u32,u32) pairs by .0 ascending, in place. */
 int msm_amd_sort_buckets_indices(msm_amd_ctx* ctx, uint32_t* pairs, size_t n_pairs);
+/* The same sort on a device-resident buffer, in place (the measured form of the stage: what
+ * benches/sort_buckets_indices_benchmark.rs:10-32 times around the reference's CPU sort).  Only the low
+ * key_bits bits of the key are sorted on (32 = full keys incl. the 0xFFFFFFFF sentinels; 8 bits per pass).
+ * kernel_ms (optional) receives the device time of the sort. */
+int msm_amd_sort_pairs_device(msm_amd_ctx* ctx, void* d_pairs, size_t n_pairs, uint32_t key_bits, float* kernel_ms);
 /* bucket_wise_accumulation (bucket_wise_accumulation.rs:26-107): pairs sorted by bucket; points
  * n_points x 24 u32 Jacobian BE32; buckets_out total_buckets x 24 u32 (untouched buckets = all zero,
  * i.e. z = 0, as Metal's zero-filled buffers give the reference). */

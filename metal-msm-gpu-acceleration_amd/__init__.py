@@ -14,7 +14,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_uint32, c_uint
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmsm_amd.so")
 
-OK, DEVICE_NOT_FOUND, LIBRARY_ERROR, FUNCTION_ERROR, PIPELINE_ERROR, INPUT_ERROR = range(6)
+(OK, DEVICE_NOT_FOUND, LIBRARY_ERROR, FUNCTION_ERROR, PIPELINE_ERROR, INPUT_ERROR, FILE_OPEN_ERROR,
+ DESERIALIZATION_ERROR, INVALID_DATA) = range(9)
 SCALAR_MONT_LE, SCALAR_CANON_LE, SCALAR_CANON_BE32 = 0, 1, 2
 POINT_H2C_AFFINE, POINT_ARK_PROJECTIVE, POINT_ARK_AFFINE, POINT_JAC_BE32 = 0, 1, 2, 3
 POINT_BYTES = {POINT_H2C_AFFINE: 64, POINT_ARK_PROJECTIVE: 96, POINT_ARK_AFFINE: 72, POINT_JAC_BE32: 96}
@@ -39,6 +40,9 @@ EXPORTS = [
     "msm_amd_sum_reduction", "msm_amd_final_accumulation", "msm_amd_test_op", "msm_amd_test_op_host",
     "msm_amd_last_timings",
     "msm_amd_algorithmic_bytes", "msm_amd_version",
+    "msm_amd_instances_save", "msm_amd_instances_open", "msm_amd_instances_count", "msm_amd_instances_size",
+    "msm_amd_instances_read", "msm_amd_instances_close", "msm_amd_instances_default_path", "msm_amd_to_wire",
+    "msm_amd_from_wire", "msm_amd_sort_pairs_device",
 ]
 
 
@@ -72,6 +76,21 @@ def _lib():
         L.msm_amd_last_error.argtypes = [c_void_p]
         L.msm_amd_version.restype = c_char_p
         L.msm_amd_init.argtypes = [c_int, POINTER(c_void_p)]
+        L.msm_amd_sort_pairs_device.argtypes = [c_void_p, c_void_p, c_size_t, c_uint32, POINTER(c_float)]
+        L.msm_amd_instances_save.argtypes = [c_char_p, c_size_t, POINTER(c_size_t), POINTER(c_void_p),
+                                             POINTER(c_void_p)]
+        L.msm_amd_instances_open.argtypes = [c_char_p, POINTER(c_void_p)]
+        L.msm_amd_instances_count.argtypes = [c_void_p]
+        L.msm_amd_instances_count.restype = c_size_t
+        L.msm_amd_instances_size.argtypes = [c_void_p, c_size_t]
+        L.msm_amd_instances_size.restype = c_size_t
+        L.msm_amd_instances_read.argtypes = [c_void_p, c_size_t, c_void_p, c_void_p]
+        L.msm_amd_instances_close.argtypes = [c_void_p]
+        L.msm_amd_instances_close.restype = None
+        L.msm_amd_instances_default_path.argtypes = [c_char_p, c_uint32, c_uint32, c_char_p, c_size_t]
+        L.msm_amd_instances_default_path.restype = c_size_t
+        L.msm_amd_to_wire.argtypes = [c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
+        L.msm_amd_from_wire.argtypes = [c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
         L.msm_amd_init_reusable.argtypes = [POINTER(c_void_p)]
         L.msm_amd_get_global.argtypes = [POINTER(c_void_p)]
         L.msm_amd_destroy.argtypes = [c_void_p]
@@ -251,6 +270,12 @@ class MsmConfig:
         buf = _u32buf(flat)
         self._check(_lib().msm_amd_sort_buckets_indices(self.h, buf, len(pairs)))
         return [(buf[2 * i], buf[2 * i + 1]) for i in range(len(pairs))]
+
+    def sort_pairs_device(self, d_pairs, n_pairs, key_bits=32) -> float:
+        """In-place device sort of (key, value) u32 pairs; returns the device time in ms."""
+        ms = c_float()
+        self._check(_lib().msm_amd_sort_pairs_device(self.h, c_void_p(d_pairs), n_pairs, key_bits, ctypes.byref(ms)))
+        return ms.value
 
     def bucket_wise_accumulation(self, sorted_pairs, points_be32, n_points, total_buckets):
         flat = [v for pr in sorted_pairs for v in pr]

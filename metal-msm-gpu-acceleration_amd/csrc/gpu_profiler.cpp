@@ -2,7 +2,7 @@
 // arguments and the same two report lines:
 //
 //   gpu_profiler [log_size=16] [num_instances=1] [mode=gpu] [retries=3] [parallel=false]
-//                [--seed S] [--device D] [--window C] [--layout h2c|ark] [--json]
+//                [--seed S] [--device D] [--window C] [--layout h2c|ark] [--json] [--vec-dir DIR | --vec-cache]
 //
 // Modes (gpu_profiler.rs:143-172)
 //   gpu       metal::msm::gpu_msm_h2c      -> msm_amd_gpu_msm_h2c (host buffers, upload included)
@@ -28,6 +28,8 @@
 
 #include "../../include/msm_amd.h"
 
+static std::vector<size_t> ns_of(unsigned count, size_t n) { return std::vector<size_t>(count, n); }
+
 static void die(msm_amd_ctx* ctx, int st, const char* what) {
   std::fprintf(stderr, "[ERROR] %s: %s %s\n", what, msm_amd_strerror(st), ctx ? msm_amd_last_error(ctx) : "");
   std::exit(1);
@@ -39,6 +41,8 @@ int main(int argc, char** argv) {
   int device = -1, window = 0;
   bool json = false;
   bool ark = false;   // --layout ark: ark_bn254 G1Projective points (96 B, z = one), config 5 of BASELINE.json
+  bool use_vecs = false;   // --vec-dir DIR | --vec-cache: inputs come from / go to the reference's instance file
+  std::string vec_dir;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 0);
@@ -46,6 +50,8 @@ int main(int argc, char** argv) {
     else if (a == "--window" && i + 1 < argc) window = std::atoi(argv[++i]);
     else if (a == "--layout" && i + 1 < argc) ark = std::string(argv[++i]) == "ark";
     else if (a == "--json") json = true;
+    else if (a == "--vec-dir" && i + 1 < argc) { use_vecs = true; vec_dir = argv[++i]; }
+    else if (a == "--vec-cache") use_vecs = true;   // $HOME/.msm_gpu_acceleration/msm_vecs, like the reference
     else pos.push_back(a);
   }
   // positional parsing with the reference's defaults (gpu_profiler.rs:24-63)
@@ -115,6 +121,70 @@ int main(int argc, char** argv) {
       if ((st = msm_amd_copy_to_device(ctx, d_pts[j], proj.data(), n * 96))) die(ctx, st, "copy_to_device");
     }
   }
+  // get_or_create_msm_instances (preprocess.rs:143-202): wire-layout inputs from msm_{log}x{n}.bin, written
+  // from the generated instances when the file does not exist yet
+  int sc_layout = MSM_AMD_SCALAR_MONT_LE;
+  int pt_layout = ark ? MSM_AMD_POINT_ARK_PROJECTIVE : MSM_AMD_POINT_H2C_AFFINE;
+  if (use_vecs) {
+    if (ark || (mode != "gpu" && mode != "gpu_resident")) {
+      std::fprintf(stderr, "[ERROR] instance files feed the gpu / gpu_resident modes (wire layout)\n");
+      return 1;
+    }
+    char path[4096];
+    if (!msm_amd_instances_default_path(vec_dir.empty() ? nullptr : vec_dir.c_str(), log_size, num_instances, path,
+                                        sizeof path)) {
+      std::fprintf(stderr, "[ERROR] instance path too long\n");
+      return 1;
+    }
+    std::vector<std::vector<uint8_t>> w_pts(num_instances), w_sc(num_instances);
+    for (unsigned j = 0; j < num_instances; ++j) {
+      w_pts[j].resize(n * 96);
+      w_sc[j].resize(n * 32);
+    }
+    msm_amd_instance_file* file = nullptr;
+    st = msm_amd_instances_open(path, &file);
+    if (st == MSM_AMD_OK) {
+      std::fprintf(stderr, "[INFO] Loading MSM instances from file: %s\n", path);
+      if (msm_amd_instances_count(file) != num_instances || msm_amd_instances_size(file, 0) != n) {
+        std::fprintf(stderr, "[ERROR] Invalid data: File mismatch: has instance_size=%zu and num_instances=%zu, "
+                             "need %u & %u\n",
+                     msm_amd_instances_size(file, 0), msm_amd_instances_count(file), log_size, num_instances);
+        return 1;
+      }
+      for (unsigned j = 0; j < num_instances; ++j) {
+        if (msm_amd_instances_size(file, j) != n) die(ctx, MSM_AMD_INVALID_DATA, "instance size");
+        if ((st = msm_amd_instances_read(file, j, w_pts[j].data(), w_sc[j].data()))) die(ctx, st, "instances_read");
+      }
+      msm_amd_instances_close(file);
+    } else if (st == MSM_AMD_FILE_OPEN_ERROR) {
+      std::fprintf(stderr, "[INFO] Saving MSM instances to file: %s\n", path);
+      std::vector<uint8_t> hp(n * 64), hs(n * 32);
+      std::vector<const void*> wp(num_instances), wsp(num_instances);
+      for (unsigned j = 0; j < num_instances; ++j) {
+        if ((st = msm_amd_copy_to_host(ctx, hp.data(), d_pts[j], n * 64))) die(ctx, st, "copy_to_host");
+        if ((st = msm_amd_copy_to_host(ctx, hs.data(), d_sc[j], n * 32))) die(ctx, st, "copy_to_host");
+        if ((st = msm_amd_to_wire(MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, hs.data(), hp.data(), n,
+                                  w_sc[j].data(), w_pts[j].data())))
+          die(ctx, st, "to_wire");
+        wp[j] = w_pts[j].data();
+        wsp[j] = w_sc[j].data();
+      }
+      if ((st = msm_amd_instances_save(path, num_instances, ns_of(num_instances, n).data(), wp.data(), wsp.data())))
+        die(ctx, st, "instances_save (does the directory exist?)");
+    } else {
+      die(ctx, st, "instances_open");
+    }
+    sc_layout = MSM_AMD_SCALAR_CANON_BE32;
+    pt_layout = MSM_AMD_POINT_JAC_BE32;
+    for (unsigned j = 0; j < num_instances; ++j) {
+      msm_amd_device_free(ctx, d_pts[j]);
+      if ((st = msm_amd_device_alloc(ctx, n * 96, &d_pts[j]))) die(ctx, st, "device_alloc");
+      if ((st = msm_amd_copy_to_device(ctx, d_pts[j], w_pts[j].data(), n * 96))) die(ctx, st, "copy_to_device");
+      if ((st = msm_amd_copy_to_device(ctx, d_sc[j], w_sc[j].data(), n * 32))) die(ctx, st, "copy_to_device");
+    }
+    h_pts = std::move(w_pts);
+    h_sc = std::move(w_sc);
+  }
   std::vector<uint8_t> out((size_t)num_instances * 96);
   std::vector<const void*> sp(num_instances), pp(num_instances);
   std::vector<size_t> ns(num_instances, n);
@@ -124,12 +194,13 @@ int main(int argc, char** argv) {
     if (mode == "gpu") {
       if (parallel) {
         for (unsigned j = 0; j < num_instances; ++j) { sp[j] = h_sc[j].data(); pp[j] = h_pts[j].data(); }
-        st = msm_amd_msm_batch(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, num_instances, sp.data(),
-                               pp.data(), ns.data(), out.data());
+        st = msm_amd_msm_batch(ctx, sc_layout, pt_layout, num_instances, sp.data(), pp.data(), ns.data(), out.data());
         if (st) die(ctx, st, "msm_batch");
       } else {
         for (unsigned j = 0; j < num_instances; ++j) {   // sequential runs (gpu_profiler.rs:104-106)
-          st = msm_amd_gpu_msm_h2c(ctx, h_sc[j].data(), h_pts[j].data(), n, out.data() + (size_t)j * 96);
+          st = use_vecs ? msm_amd_msm(ctx, sc_layout, pt_layout, h_sc[j].data(), h_pts[j].data(), n,
+                                      out.data() + (size_t)j * 96)
+                        : msm_amd_gpu_msm_h2c(ctx, h_sc[j].data(), h_pts[j].data(), n, out.data() + (size_t)j * 96);
           if (st) die(ctx, st, "gpu_msm_h2c");
         }
       }
@@ -155,9 +226,8 @@ int main(int argc, char** argv) {
       }
     } else {
       for (unsigned j = 0; j < num_instances; ++j) { sp[j] = d_sc[j]; pp[j] = d_pts[j]; }
-      st = msm_amd_msm_batch_device(ctx, MSM_AMD_SCALAR_MONT_LE,
-                                    ark ? MSM_AMD_POINT_ARK_PROJECTIVE : MSM_AMD_POINT_H2C_AFFINE, num_instances,
-                                    sp.data(), pp.data(), ns.data(), out.data());
+      st = msm_amd_msm_batch_device(ctx, sc_layout, pt_layout, num_instances, sp.data(), pp.data(), ns.data(),
+                                    out.data());
       if (st) die(ctx, st, "msm_batch_device");
     }
   }

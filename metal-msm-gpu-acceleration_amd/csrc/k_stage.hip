@@ -77,10 +77,32 @@ linear_scan_kernel(uint32_t* __restrict__ data, size_t len) {
   }
 }
 
+// Exclusive scan of each digit's row of the [256][num_tiles] histogram (one workgroup per digit, coalesced
+// chunks of blockDim tiles) + the digit totals; the scatter kernel adds the digit bases itself.
+__global__ void __launch_bounds__(1024)
+radix_row_scan_kernel(uint32_t* __restrict__ tile_hist, uint32_t num_tiles, uint32_t* __restrict__ digit_total) {
+  __shared__ uint32_t scratch[17];
+  uint32_t* row = tile_hist + (size_t)blockIdx.x * num_tiles;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < num_tiles; base += blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < num_tiles ? row[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, scratch, &total);
+    if (i < num_tiles) row[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
+}
+
 __global__ void __launch_bounds__(256)
 radix_scatter_kernel(const uint2* __restrict__ in, uint2* __restrict__ out, size_t n, uint32_t shift,
-                     uint32_t num_tiles, const uint32_t* __restrict__ tile_offset /* [256][num_tiles] */) {
+                     uint32_t num_tiles, const uint32_t* __restrict__ tile_offset /* [256][num_tiles] */,
+                     const uint32_t* __restrict__ digit_total /* [256] */) {
   __shared__ uint32_t wh[4][256];   // per-wave digit counts, then per-wave running write positions
+  __shared__ uint32_t scratch[17];
+  uint32_t all;
+  const uint32_t digit_base = block_exclusive_scan(digit_total[threadIdx.x], scratch, &all);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int v = 0; v < 4; ++v) wh[v][threadIdx.x] = 0;
   __syncthreads();
@@ -92,7 +114,7 @@ radix_scatter_kernel(const uint2* __restrict__ in, uint2* __restrict__ out, size
   __syncthreads();
   {
     // thread d turns the four per-wave counts of digit d into write positions
-    uint32_t run = tile_offset[(size_t)threadIdx.x * num_tiles + blockIdx.x];
+    uint32_t run = digit_base + tile_offset[(size_t)threadIdx.x * num_tiles + blockIdx.x];
     for (int v = 0; v < 4; ++v) {
       const uint32_t cnt = wh[v][threadIdx.x];
       wh[v][threadIdx.x] = run;
@@ -211,18 +233,20 @@ void launch_ref_prepare(hipStream_t st, const u256* scalars, uint32_t n, uint32_
   hipLaunchKernelGGL(ref_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, st, scalars, n, c, W, pairs);
 }
 
-// Sorts n pairs by key; a and b are ping-pong buffers of n pairs, tile_hist holds 256 * tiles words.
-// *result points to whichever buffer holds the sorted output.
-void launch_radix_sort_pairs(hipStream_t st, uint2* a, uint2* b, size_t n, uint32_t* tile_hist, uint2** result) {
+// Sorts n pairs by the low key_bits bits of the key; a and b are ping-pong buffers of n pairs, tile_hist holds
+// 256 * (tiles + 1) words.  *result points to whichever buffer holds the sorted output.
+void launch_radix_sort_pairs(hipStream_t st, uint2* a, uint2* b, size_t n, uint32_t* tile_hist, uint2** result,
+                             uint32_t key_bits) {
   const uint32_t tiles = (uint32_t)((n + kRadixTile - 1) / kRadixTile);
+  uint32_t* digit_total = tile_hist + (size_t)tiles * 256;
   uint2* src = a;
   uint2* dst = b;
-  for (uint32_t shift = 0; shift < 32; shift += 8) {
+  for (uint32_t shift = 0; shift < key_bits; shift += 8) {
     hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(256), 0, st, (const uint2*)src, n, shift, tiles,
                        tile_hist);
-    hipLaunchKernelGGL(linear_scan_kernel, dim3(1), dim3(1024), 0, st, tile_hist, (size_t)tiles * 256);
+    hipLaunchKernelGGL(radix_row_scan_kernel, dim3(256), dim3(1024), 0, st, tile_hist, tiles, digit_total);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(256), 0, st, (const uint2*)src, dst, n, shift, tiles,
-                       (const uint32_t*)tile_hist);
+                       (const uint32_t*)tile_hist, (const uint32_t*)digit_total);
     uint2* t = src;
     src = dst;
     dst = t;

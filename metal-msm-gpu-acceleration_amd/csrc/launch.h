@@ -75,7 +75,8 @@ void launch_gen_instance(hipStream_t st, uint64_t seed, uint32_t n, int scalars_
 constexpr int kRadixItems = 16;
 constexpr int kRadixTile = 256 * kRadixItems;
 void launch_ref_prepare(hipStream_t st, const u256* scalars, uint32_t n, uint32_t c, uint32_t W, uint2* pairs);
-void launch_radix_sort_pairs(hipStream_t st, uint2* a, uint2* b, size_t n, uint32_t* tile_hist, uint2** result);
+void launch_radix_sort_pairs(hipStream_t st, uint2* a, uint2* b, size_t n, uint32_t* tile_hist, uint2** result,
+                             uint32_t key_bits = 32);
 void launch_ref_accumulate(hipStream_t st, const uint2* pairs, size_t n_pairs, const Jacobian* points,
                            uint32_t n_points, uint32_t total_buckets, Jacobian* buckets);
 void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t lb, PtI* out);

@@ -616,6 +616,9 @@ const char* msm_amd_strerror(int status) {
     case MSM_AMD_FUNCTION_ERROR: return "Couldn't set up a kernel function (MetalError::FunctionError)";
     case MSM_AMD_PIPELINE_ERROR: return "HIP launch/runtime failure (MetalError::PipelineError)";
     case MSM_AMD_INPUT_ERROR: return "Invalid input (MetalError::InputError)";
+    case MSM_AMD_FILE_OPEN_ERROR: return "I/O error (HarnessError::FileOpenError)";
+    case MSM_AMD_DESERIALIZATION_ERROR: return "Data in file is invalid or incomplete (HarnessError::DeserializationError)";
+    case MSM_AMD_INVALID_DATA: return "Invalid data (HarnessError::InvalidData)";
   }
   return "unknown status";
 }
@@ -962,7 +965,7 @@ int msm_amd_sort_buckets_indices(msm_amd_ctx* ctx, uint32_t* pairs, size_t n_pai
   const uint32_t tiles = (uint32_t)((n_pairs + kRadixTile - 1) / kRadixTile);
   if ((rc = ensure(ctx, ctx->scratch_a, n_pairs * 8))) return rc;
   if ((rc = ensure(ctx, ctx->scratch_b, n_pairs * 8))) return rc;
-  if ((rc = ensure(ctx, ctx->scratch_c, (size_t)tiles * 256 * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_c, ((size_t)tiles + 1) * 256 * 4))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_a.p, pairs, n_pairs * 8, hipMemcpyHostToDevice, st));
   uint2* src = nullptr;
   launch_radix_sort_pairs(st, (uint2*)ctx->scratch_a.p, (uint2*)ctx->scratch_b.p, n_pairs,
@@ -970,6 +973,39 @@ int msm_amd_sort_buckets_indices(msm_amd_ctx* ctx, uint32_t* pairs, size_t n_pai
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(pairs, src, n_pairs * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  return MSM_AMD_OK;
+}
+
+int msm_amd_sort_pairs_device(msm_amd_ctx* ctx, void* d_pairs, size_t n_pairs, uint32_t key_bits, float* kernel_ms) {
+  if (!ctx || !d_pairs || key_bits == 0 || key_bits > 32) return fail(ctx, MSM_AMD_INPUT_ERROR, "bad sort arguments");
+  if (kernel_ms) *kernel_ms = 0.f;
+  if (n_pairs == 0) return MSM_AMD_OK;
+  if (n_pairs > 0xFFFFFFFFull) return fail(ctx, MSM_AMD_INPUT_ERROR, "too many pairs");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  const uint32_t tiles = (uint32_t)((n_pairs + kRadixTile - 1) / kRadixTile);
+  if ((rc = ensure(ctx, ctx->scratch_b, n_pairs * 8))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_c, ((size_t)tiles + 1) * 256 * 4))) return rc;
+  hipEvent_t e0, e1;
+  HIP_TRY(ctx, hipEventCreate(&e0));
+  HIP_TRY(ctx, hipEventCreate(&e1));
+  HIP_TRY(ctx, hipEventRecord(e0, st));
+  uint2* src = nullptr;
+  launch_radix_sort_pairs(st, (uint2*)d_pairs, (uint2*)ctx->scratch_b.p, n_pairs, (uint32_t*)ctx->scratch_c.p, &src,
+                          key_bits);
+  hipError_t le = hipGetLastError();
+  if (le == hipSuccess && src != (uint2*)d_pairs)   // odd number of passes: the result sits in the scratch buffer
+    le = hipMemcpyAsync(d_pairs, src, n_pairs * 8, hipMemcpyDeviceToDevice, st);
+  if (le == hipSuccess) le = hipEventRecord(e1, st);
+  if (le == hipSuccess) le = hipStreamSynchronize(st);
+  float ms = 0.f;
+  if (le == hipSuccess) le = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  HIP_TRY(ctx, le);
+  if (kernel_ms) *kernel_ms = ms;
   return MSM_AMD_OK;
 }
 

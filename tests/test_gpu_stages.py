@@ -151,3 +151,25 @@ def test_stage_chain_equals_msm(cfg, msm_pkg):
     res = cfg.sum_reduction(sum(buckets, []), bl, W)
     out = msm_pkg.final_accumulation(sum(res, []), W, c)
     assert decode_be32_affine(out) == o.msm_naive(sc, pts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,key_bits", [(1, 32), (257, 32), (70001, 20), (17 << 12, 24), (300000, 32)])
+def test_sort_pairs_device_in_place(cfg, n, key_bits):
+    """Device-resident form of sort_buckets_indices (sort_buckets.rs:15-34 / the reference's sort benchmark):
+    ascending keys, same multiset of pairs (the sort post-conditions of sort_buckets.rs:111-125), stable."""
+    import numpy as np
+    rng = np.random.default_rng(42 + n)
+    pairs = np.empty((n, 2), dtype=np.uint32)
+    pairs[:, 0] = rng.integers(0, 1 << key_bits, size=n, dtype=np.uint64).astype(np.uint32)
+    if key_bits == 32 and n > 4:
+        pairs[::7, 0] = 0xFFFFFFFF        # the zero-digit sentinels sort last
+    pairs[:, 1] = np.arange(n, dtype=np.uint32)
+    d = cfg.alloc(8 * n)
+    cfg.to_device(d, pairs.tobytes())
+    ms = cfg.sort_pairs_device(d, n, key_bits)
+    got = np.frombuffer(cfg.to_host(d, 8 * n), dtype=np.uint32).reshape(n, 2)
+    cfg.free(d)
+    assert ms >= 0
+    order = np.argsort(pairs[:, 0], kind="stable")
+    assert np.array_equal(got, pairs[order])
