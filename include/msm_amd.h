@@ -55,7 +55,9 @@ enum {
   MSM_AMD_POINT_ARK_PROJECTIVE = 1, /* ark_bn254::G1Projective {x,y,z}: 96 B Jacobian, Montgomery LE
                                        (limbs_conversion.rs:123-130) */
   MSM_AMD_POINT_ARK_AFFINE = 2,     /* ark_bn254::G1Affine {x,y,infinity:bool}: 72 B (limbs_conversion.rs:132-137) */
-  MSM_AMD_POINT_JAC_BE32 = 3        /* reference wire layout: 24 x u32 (x,y,z each MS-limb first), Montgomery */
+  MSM_AMD_POINT_JAC_BE32 = 3,       /* reference wire layout: 24 x u32 (x,y,z each MS-limb first), Montgomery */
+  MSM_AMD_POINT_PREPARED = 4        /* device-only: 64-byte records written by msm_amd_bases_upload /
+                                       msm_amd_bases_prepare_device (opaque internal form of affine points) */
 };
 
 /* Per-stage device times of the last MSM on this ctx, milliseconds, from hipEvents on the ctx stream
@@ -143,6 +145,17 @@ int msm_amd_submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_l
                                 const void* const* d_scalars, const void* const* d_points, const size_t* n,
                                 void* out_host, int* ticket);
 int msm_amd_wait_batch(msm_amd_ctx* ctx, int ticket);
+
+/* ---- persistent bases -----------------------------------------------------------------------
+ * The reference converts and re-uploads the bases on every call (msm.rs:152-153); provers reuse one SRS for
+ * many MSMs.  These calls convert a point array once into the library's internal 64-byte form, resident on the
+ * device; pass the result as d_points with MSM_AMD_POINT_PREPARED to the *_device entry points, or use
+ * msm_amd_msm_prepared with host scalars.  Prepared arrays are freed with msm_amd_device_free. */
+int msm_amd_bases_upload(msm_amd_ctx* ctx, int point_layout, const void* points, size_t n, void** d_prepared);
+int msm_amd_bases_prepare_device(msm_amd_ctx* ctx, int point_layout, const void* d_points, size_t n,
+                                 void* d_prepared /* n x 64 bytes */);
+int msm_amd_msm_prepared(msm_amd_ctx* ctx, int scalar_layout, const void* scalars, const void* d_prepared, size_t n,
+                         void* out96);
 
 /* ---- device memory helpers (so callers without a HIP binding can stage data) ------------------ */
 int msm_amd_device_alloc(msm_amd_ctx* ctx, size_t bytes, void** d_ptr);

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_amd.so")
 (OK, DEVICE_NOT_FOUND, LIBRARY_ERROR, FUNCTION_ERROR, PIPELINE_ERROR, INPUT_ERROR, FILE_OPEN_ERROR,
  DESERIALIZATION_ERROR, INVALID_DATA) = range(9)
 SCALAR_MONT_LE, SCALAR_CANON_LE, SCALAR_CANON_BE32 = 0, 1, 2
-POINT_H2C_AFFINE, POINT_ARK_PROJECTIVE, POINT_ARK_AFFINE, POINT_JAC_BE32 = 0, 1, 2, 3
+POINT_H2C_AFFINE, POINT_ARK_PROJECTIVE, POINT_ARK_AFFINE, POINT_JAC_BE32, POINT_PREPARED = 0, 1, 2, 3, 4
 POINT_BYTES = {POINT_H2C_AFFINE: 64, POINT_ARK_PROJECTIVE: 96, POINT_ARK_AFFINE: 72, POINT_JAC_BE32: 96}
 (OP_UINT_ADD, OP_UINT_SUB, OP_UINT_PROD, OP_UINT_SHL, OP_UINT_SHR, OP_FP_ADD, OP_FP_SUB, OP_FP_MUL, OP_FP_NEG,
  OP_FP_POW, OP_EC_ADD, OP_EC_MUL, OP_EC_MADD, OP_EC_DBL, OP_FP29_MUL, OP_FP29_SQR, OP_FP29_SUB_K4E30,
@@ -42,7 +42,8 @@ EXPORTS = [
     "msm_amd_algorithmic_bytes", "msm_amd_version",
     "msm_amd_instances_save", "msm_amd_instances_open", "msm_amd_instances_count", "msm_amd_instances_size",
     "msm_amd_instances_read", "msm_amd_instances_close", "msm_amd_instances_default_path", "msm_amd_to_wire",
-    "msm_amd_from_wire", "msm_amd_sort_pairs_device",
+    "msm_amd_from_wire", "msm_amd_sort_pairs_device", "msm_amd_bases_upload", "msm_amd_bases_prepare_device",
+    "msm_amd_msm_prepared",
 ]
 
 
@@ -76,6 +77,9 @@ def _lib():
         L.msm_amd_last_error.argtypes = [c_void_p]
         L.msm_amd_version.restype = c_char_p
         L.msm_amd_init.argtypes = [c_int, POINTER(c_void_p)]
+        L.msm_amd_bases_upload.argtypes = [c_void_p, c_int, c_void_p, c_size_t, POINTER(c_void_p)]
+        L.msm_amd_bases_prepare_device.argtypes = [c_void_p, c_int, c_void_p, c_size_t, c_void_p]
+        L.msm_amd_msm_prepared.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
         L.msm_amd_sort_pairs_device.argtypes = [c_void_p, c_void_p, c_size_t, c_uint32, POINTER(c_float)]
         L.msm_amd_instances_save.argtypes = [c_char_p, c_size_t, POINTER(c_size_t), POINTER(c_void_p),
                                              POINTER(c_void_p)]
@@ -270,6 +274,23 @@ class MsmConfig:
         buf = _u32buf(flat)
         self._check(_lib().msm_amd_sort_buckets_indices(self.h, buf, len(pairs)))
         return [(buf[2 * i], buf[2 * i + 1]) for i in range(len(pairs))]
+
+    # ---- persistent bases (the reference re-uploads them per call, msm.rs:152-153) -----------
+    def bases_upload(self, points: bytes, n: int, point_layout=POINT_H2C_AFFINE) -> int:
+        """Convert once, keep resident; returns a device pointer to pass with POINT_PREPARED (free with .free)."""
+        p = c_void_p()
+        self._check(_lib().msm_amd_bases_upload(self.h, point_layout, points, n, ctypes.byref(p)))
+        return p.value
+
+    def bases_prepare_device(self, d_points, n, point_layout=POINT_H2C_AFFINE) -> int:
+        out = self.alloc(64 * n)
+        self._check(_lib().msm_amd_bases_prepare_device(self.h, point_layout, c_void_p(d_points), n, c_void_p(out)))
+        return out
+
+    def msm_prepared(self, scalars: bytes, d_prepared, n, scalar_layout=SCALAR_MONT_LE) -> bytes:
+        out = ctypes.create_string_buffer(96)
+        self._check(_lib().msm_amd_msm_prepared(self.h, scalar_layout, scalars, c_void_p(d_prepared), n, out))
+        return out.raw
 
     def sort_pairs_device(self, d_pairs, n_pairs, key_bits=32) -> float:
         """In-place device sort of (key, value) u32 pairs; returns the device time in ms."""

@@ -84,7 +84,7 @@ struct msm_amd_ctx {
   std::string last_error;
   uint32_t forced_window = 0;
   int next_ws = 0;
-  DeviceBuf scratch_a, scratch_b, scratch_c;
+  DeviceBuf scratch_a, scratch_b, scratch_c, scratch_b2, scratch_c2;
   Batch batches[kMaxBatches];
   msm_amd_timings timings{};
 };
@@ -305,6 +305,9 @@ int convert_inputs(msm_amd_ctx* ctx, Workspace& w, hipStream_t st, int scalar_la
       return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown scalar layout");
   }
   switch (point_layout) {
+    case MSM_AMD_POINT_PREPARED:   // already in the internal packed form (msm_amd_bases_*): nothing to convert
+      *points_native = nullptr;
+      break;
     case MSM_AMD_POINT_H2C_AFFINE:
       *points_native = (const Affine*)d_points;
       break;
@@ -343,6 +346,7 @@ size_t scalar_bytes(int) { return 32; }
 size_t point_bytes(int layout) {
   switch (layout) {
     case MSM_AMD_POINT_H2C_AFFINE: return 64;
+    case MSM_AMD_POINT_PREPARED: return sizeof(AffPacked);
     case MSM_AMD_POINT_ARK_PROJECTIVE: return 96;
     case MSM_AMD_POINT_ARK_AFFINE: return 72;
     case MSM_AMD_POINT_JAC_BE32: return 96;
@@ -385,7 +389,8 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   if ((rc = ensure(ctx, w.order, p.max_items * sizeof(uint2)))) return rc;
   if ((rc = ensure(ctx, w.multi_list, p.max_items * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.counters, sizeof(PlanCounters)))) return rc;
-  if ((rc = ensure(ctx, w.bases29, n * sizeof(AffPacked)))) return rc;
+  const bool prepared = point_layout == MSM_AMD_POINT_PREPARED;
+  if (!prepared && (rc = ensure(ctx, w.bases29, n * sizeof(AffPacked)))) return rc;
   if ((rc = ensure(ctx, w.buckets, p.total_buckets * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.item_partials, p.max_items * sizeof(PtI)))) return rc;
   SortBuffers sb{};
@@ -423,7 +428,8 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   int sc_mont = 0;
   if ((rc = convert_inputs(ctx, w, fs, scalar_layout, point_layout, d_scalars, d_points, n, &sc, &sc_mont, &pts)))
     return rc;
-  launch_convert_bases(fs, pts, p.n, (AffPacked*)w.bases29.p);   // external 8 x u32 -> packed internal domain
+  const AffPacked* bases = prepared ? (const AffPacked*)d_points : (const AffPacked*)w.bases29.p;
+  if (!prepared) launch_convert_bases(fs, pts, p.n, (AffPacked*)w.bases29.p);   // external 8 x u32 -> packed internal domain
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_CONVERT], fs));
   launch_digits(fs, p, sc, sc_mont, sb.digits);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_DIGITS], fs));
@@ -438,7 +444,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
     w.reduce_pending = false;
   }
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC_S], st));
-  launch_accumulate(st, p, (const AffPacked*)w.bases29.p, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p,
+  launch_accumulate(st, p, bases, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p,
                     ctx->overlap_front, slot.ev[EV_ACC_K0], slot.ev[EV_ACC_K1]);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
   HIP_TRY(ctx, hipEventRecord(w.acc_done, st));
@@ -569,35 +575,61 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
     return fail(ctx, MSM_AMD_INPUT_ERROR, "null argument or empty batch");
   const size_t pb = point_bytes(point_layout);
   if (pb == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown point layout");
+  if (point_layout == MSM_AMD_POINT_PREPARED)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "prepared bases live on the device: use msm_amd_msm_prepared");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  for (size_t i = 0; i < n_inst; ++i) {
+  for (size_t i = 0; i < n_inst; ++i)
     if (n[i] == 0 || !scalars[i] || !points[i]) return fail(ctx, MSM_AMD_INPUT_ERROR, "n == 0 or null pointer");
+  // Two staging sets: instance i + 1 is uploaded (and its front end enqueued) while instance i computes; the
+  // pageable-memory copies block the host, not the GPU.
+  int tickets[2] = {-1, -1};
+  msm_amd_timings avg{};
+  auto collect = [&](size_t i) {   // wait for instance i and fold its stage times into the running average
+    int rc = wait_batch(ctx, tickets[i & 1]);
+    if (rc) return rc;
+    const msm_amd_timings& T = ctx->timings;
+    const float a = (float)i / (float)(i + 1), b = 1.0f / (float)(i + 1);
+    msm_amd_timings k = T;
+    k.convert_ms = avg.convert_ms * a + T.convert_ms * b;
+    k.digits_ms = avg.digits_ms * a + T.digits_ms * b;
+    k.sort_ms = avg.sort_ms * a + T.sort_ms * b;
+    k.accumulate_ms = avg.accumulate_ms * a + T.accumulate_ms * b;
+    k.accumulate_kernel_ms = avg.accumulate_kernel_ms * a + T.accumulate_kernel_ms * b;
+    k.reduce_ms = avg.reduce_ms * a + T.reduce_ms * b;
+    k.final_ms = avg.final_ms * a + T.final_ms * b;
+    k.total_gpu_ms = avg.total_gpu_ms * a + T.total_gpu_ms * b;
+    k.reserved = (uint32_t)(i + 1);
+    avg = k;
+    return (int)MSM_AMD_OK;
+  };
+  auto bail = [&](int rc) {   // error exit: nothing of this call may stay in flight or hold a ticket
+    (void)hipDeviceSynchronize();
+    for (int t : tickets)
+      if (t >= 0) ctx->batches[t].active = false;
+    return rc;
+  };
+  for (size_t i = 0; i < n_inst; ++i) {
+    DeviceBuf& sbuf = (i & 1) ? ctx->scratch_b2 : ctx->scratch_b;
+    DeviceBuf& pbuf = (i & 1) ? ctx->scratch_c2 : ctx->scratch_c;
     int rc;
-    if ((rc = ensure(ctx, ctx->scratch_b, n[i] * scalar_bytes(scalar_layout)))) return rc;
-    if ((rc = ensure(ctx, ctx->scratch_c, n[i] * pb))) return rc;
+    if ((rc = ensure(ctx, sbuf, n[i] * scalar_bytes(scalar_layout)))) return bail(rc);
+    if ((rc = ensure(ctx, pbuf, n[i] * pb))) return bail(rc);
     // uploads go on the stream the front end runs on, so conversion / digits see them in order
     hipStream_t up = ctx->overlap_front ? ctx->front_stream : ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars[i], n[i] * scalar_bytes(scalar_layout),
-                                hipMemcpyHostToDevice, up));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, points[i], n[i] * pb, hipMemcpyHostToDevice, up));
-    const void* ds = ctx->scratch_b.p;
-    const void* dp = ctx->scratch_c.p;
-    msm_amd_timings keep = ctx->timings;
-    rc = run_batch_device(ctx, scalar_layout, point_layout, 1, &ds, &dp, &n[i], (uint8_t*)out + i * 96);
-    if (rc) return rc;
-    if (i > 0) {   // keep a running per-MSM average over the host-side batch
-      msm_amd_timings& T = ctx->timings;
-      const float a = (float)i / (float)(i + 1), b = 1.0f / (float)(i + 1);
-      T.convert_ms = keep.convert_ms * a + T.convert_ms * b;
-      T.digits_ms = keep.digits_ms * a + T.digits_ms * b;
-      T.sort_ms = keep.sort_ms * a + T.sort_ms * b;
-      T.accumulate_ms = keep.accumulate_ms * a + T.accumulate_ms * b;
-      T.reduce_ms = keep.reduce_ms * a + T.reduce_ms * b;
-      T.final_ms = keep.final_ms * a + T.final_ms * b;
-      T.total_gpu_ms = keep.total_gpu_ms * a + T.total_gpu_ms * b;
-      T.reserved = (uint32_t)(i + 1);
-    }
+    hipError_t e = hipMemcpyAsync(sbuf.p, scalars[i], n[i] * scalar_bytes(scalar_layout), hipMemcpyHostToDevice, up);
+    if (e == hipSuccess) e = hipMemcpyAsync(pbuf.p, points[i], n[i] * pb, hipMemcpyHostToDevice, up);
+    if (e != hipSuccess) return bail(fail(ctx, MSM_AMD_PIPELINE_ERROR, hipGetErrorString(e)));
+    const void* ds = sbuf.p;
+    const void* dp = pbuf.p;
+    int ticket = -1;
+    rc = submit_batch_device(ctx, scalar_layout, point_layout, 1, &ds, &dp, &n[i], (uint8_t*)out + i * 96, &ticket);
+    if (rc) return bail(rc);
+    tickets[i & 1] = ticket;
+    if (i > 0 && (rc = collect(i - 1))) return bail(rc);   // frees the other staging set for instance i + 1
   }
+  int rc = collect(n_inst - 1);
+  if (rc) return bail(rc);
+  ctx->timings = avg;
   return MSM_AMD_OK;
 }
 
@@ -718,7 +750,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (w.acc_done) (void)hipEventDestroy(w.acc_done);
     if (w.reduce_done) (void)hipEventDestroy(w.reduce_done);
   }
-  DeviceBuf* sbufs[] = {&ctx->scratch_a, &ctx->scratch_b, &ctx->scratch_c};
+  DeviceBuf* sbufs[] = {&ctx->scratch_a, &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_b2, &ctx->scratch_c2};
   for (DeviceBuf* b : sbufs)
     if (b->p) (void)hipFree(b->p);
   for (Batch& B : ctx->batches)
@@ -870,6 +902,73 @@ int msm_amd_wait_batch(msm_amd_ctx* ctx, int ticket) {
 int msm_amd_msm_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const void* d_scalars,
                        const void* d_points, size_t n, void* out96_host) {
   return msm_amd_msm_batch_device(ctx, scalar_layout, point_layout, 1, &d_scalars, &d_points, &n, out96_host);
+}
+
+// Conversion of a resident point array to the internal packed form; ctx->mu held by the caller.
+static int prepare_bases_locked(msm_amd_ctx* ctx, int point_layout, const void* d_points, size_t n, void* d_prepared) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());   // a set-up step: the conversion scratch of workspace 0 must be idle
+  hipStream_t st = ctx->stream;
+  const u256* sc = nullptr;
+  const Affine* pts = nullptr;
+  int sc_mont = 0, rc;
+  if ((rc = convert_inputs(ctx, ctx->ws[0], st, MSM_AMD_SCALAR_CANON_LE, point_layout, d_points, d_points, n, &sc,
+                           &sc_mont, &pts)))
+    return rc;
+  launch_convert_bases(st, pts, (uint32_t)n, (AffPacked*)d_prepared);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return MSM_AMD_OK;
+}
+
+int msm_amd_bases_prepare_device(msm_amd_ctx* ctx, int point_layout, const void* d_points, size_t n, void* d_prepared) {
+  if (!ctx || !d_points || !d_prepared || n == 0 || n > 0xFFFFFFFFull)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "bad bases_prepare arguments");
+  if (point_layout == MSM_AMD_POINT_PREPARED || point_bytes(point_layout) == 0)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "bad point layout");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  return prepare_bases_locked(ctx, point_layout, d_points, n, d_prepared);
+}
+
+int msm_amd_bases_upload(msm_amd_ctx* ctx, int point_layout, const void* points, size_t n, void** d_prepared) {
+  if (!ctx || !points || !d_prepared || n == 0 || n > 0xFFFFFFFFull)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "bad bases_upload arguments");
+  const size_t pb = point_bytes(point_layout);
+  if (pb == 0 || point_layout == MSM_AMD_POINT_PREPARED) return fail(ctx, MSM_AMD_INPUT_ERROR, "bad point layout");
+  *d_prepared = nullptr;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->scratch_c, n * pb))) return rc;
+  void* d_out = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d_out, n * sizeof(AffPacked)));
+  hipError_t e = hipMemcpy(ctx->scratch_c.p, points, n * pb, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(d_out);
+    HIP_TRY(ctx, e);
+  }
+  if ((rc = prepare_bases_locked(ctx, point_layout, ctx->scratch_c.p, n, d_out))) {
+    (void)hipFree(d_out);
+    return rc;
+  }
+  *d_prepared = d_out;
+  return MSM_AMD_OK;
+}
+
+int msm_amd_msm_prepared(msm_amd_ctx* ctx, int scalar_layout, const void* scalars, const void* d_prepared, size_t n,
+                         void* out96) {
+  if (!ctx || !scalars || !d_prepared || !out96 || n == 0)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "bad msm_prepared arguments");
+  if (scalar_layout < MSM_AMD_SCALAR_MONT_LE || scalar_layout > MSM_AMD_SCALAR_CANON_BE32)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown scalar layout");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->scratch_b, n * 32))) return rc;
+  hipStream_t up = ctx->overlap_front ? ctx->front_stream : ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars, n * 32, hipMemcpyHostToDevice, up));
+  const void* ds = ctx->scratch_b.p;
+  return run_batch_device(ctx, scalar_layout, MSM_AMD_POINT_PREPARED, 1, &ds, &d_prepared, &n, out96);
 }
 
 int msm_amd_device_alloc(msm_amd_ctx* ctx, size_t bytes, void** d_ptr) {

@@ -142,3 +142,38 @@ def test_device_generator_matches_oracle(cfg, msm_pkg):
     finally:
         cfg.free(dp)
         cfg.free(ds)
+
+
+def test_persistent_bases_match_the_per_call_path(cfg, msm_pkg):
+    """Bases converted once and kept resident (SURVEY §8b staged variant / §8f N4) give the same bytes as the
+    per-call conversion the reference does (msm.rs:152-153), for every input layout and for several scalar sets."""
+    n = 700
+    pts, sc = small_instance(4242, n)
+    pts[5] = None                                            # an identity among the bases
+    sb, pb = h2c_instance_bytes(pts, sc)
+    want = msm_pkg.gpu_msm_h2c(sb, pb, cfg)
+    assert o.decode_jacobian_mont_le(want) == _expect(pts, sc)
+    proj = b"".join(o.encode_projective_ark(o.to_jac(p) if p else None) for p in pts)
+    handles = [cfg.bases_upload(pb, n), cfg.bases_upload(proj, n, msm_pkg.POINT_ARK_PROJECTIVE)]
+    d_raw = cfg.alloc(len(pb))
+    cfg.to_device(d_raw, pb)
+    handles.append(cfg.bases_prepare_device(d_raw, n))
+    try:
+        for h in handles:
+            assert cfg.msm_prepared(sb, h, n) == want
+        # the same resident bases with other scalars, through the device entry point
+        sc2 = [(k * 7 + 1) % o.R_ORDER for k in sc]
+        sb2, _ = h2c_instance_bytes(pts, sc2)
+        d_sc = cfg.alloc(len(sb2))
+        cfg.to_device(d_sc, sb2)
+        (out2,) = cfg.msm_batch_device([d_sc], [handles[0]], [n], point_layout=msm_pkg.POINT_PREPARED)
+        assert out2 == msm_pkg.gpu_msm_h2c(sb2, pb, cfg)
+        cfg.free(d_sc)
+        # prepared arrays are device memory: the host-buffer entry point refuses the layout
+        with pytest.raises(msm_pkg.MsmError) as e:
+            cfg.msm(sb, pb, n, point_layout=msm_pkg.POINT_PREPARED)
+        assert e.value.status == msm_pkg.INPUT_ERROR
+    finally:
+        for h in handles:
+            cfg.free(h)
+        cfg.free(d_raw)
