@@ -77,7 +77,6 @@ combine_small_kernel(const uint32_t* __restrict__ multi_list, PlanCounters* __re
                      const uint32_t* __restrict__ bucket_size, const uint32_t* __restrict__ item_start,
                      const uint32_t* __restrict__ win_base, uint32_t lb, uint32_t CH,
                      const PtI* __restrict__ partials, PtI* __restrict__ buckets, uint32_t* __restrict__ big_list) {
-  __builtin_amdgcn_s_setprio(1);   // tail kernels share CUs with the accumulate grid: issue ahead of it
   const uint32_t count = counters->multi_count;
   for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < count; m += gridDim.x * blockDim.x) {
     const uint32_t b = multi_list[m];
@@ -99,7 +98,6 @@ combine_big_kernel(const uint32_t* __restrict__ big_list, const PlanCounters* __
                    const uint32_t* __restrict__ bucket_size, const uint32_t* __restrict__ item_start,
                    const uint32_t* __restrict__ win_base, uint32_t lb, uint32_t CH,
                    const PtI* __restrict__ partials, PtI* __restrict__ buckets) {
-  __builtin_amdgcn_s_setprio(1);   // tail kernels share CUs with the accumulate grid: issue ahead of it
   __shared__ PtI sh[64];
   const uint32_t count = counters->pad[0];
   for (uint32_t m = blockIdx.x; m < count; m += gridDim.x) {

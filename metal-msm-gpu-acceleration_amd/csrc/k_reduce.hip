@@ -12,7 +12,6 @@ namespace msm_amd {
 __global__ void __launch_bounds__(64)
 reduce_seg_kernel(const PtI* __restrict__ buckets, uint32_t total_segs,
                   PtI* __restrict__ S, PtI* __restrict__ T) {
-  __builtin_amdgcn_s_setprio(1);   // tail kernels share CUs with the accumulate grid: issue ahead of it
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= total_segs) return;
   const PtI* X = buckets + (size_t)s * kSeg;
@@ -37,7 +36,6 @@ reduce_seg_kernel(const PtI* __restrict__ buckets, uint32_t total_segs,
 __global__ void __launch_bounds__(512)
 reduce_tree_kernel(const PtI* __restrict__ S, const PtI* __restrict__ T, uint32_t nseg,
                    uint32_t K, Jacobian* __restrict__ partial) {
-  __builtin_amdgcn_s_setprio(1);   // tail kernels share CUs with the accumulate grid: issue ahead of it
   extern __shared__ uint32_t lds_u32[];
   PtI* sh = reinterpret_cast<PtI*>(lds_u32);
   const uint32_t k = blockIdx.x, w = blockIdx.y;
