@@ -12,7 +12,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsm_amd.so")
+# MSM_AMD_LIB points development A/B runs at another build of the same library; the default is the in-tree one
+LIB_PATH = os.environ.get("MSM_AMD_LIB") or os.path.join(_HERE, "libmsm_amd.so")
 
 (OK, DEVICE_NOT_FOUND, LIBRARY_ERROR, FUNCTION_ERROR, PIPELINE_ERROR, INPUT_ERROR, FILE_OPEN_ERROR,
  DESERIALIZATION_ERROR, INVALID_DATA) = range(9)

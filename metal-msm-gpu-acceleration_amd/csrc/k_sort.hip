@@ -20,6 +20,7 @@ constexpr int kSortThreads = 1024;       // hist / plan / scatter workgroup size
 __global__ void __launch_bounds__(256)
 digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W, int scalars_mont,
               uint16_t* __restrict__ digits) {
+  __builtin_amdgcn_s_setprio(3);   // shares SIMDs with the accumulate grid, whose straight-line code would starve it of issue slots
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   u256 k = load_u256(&scalars[t]);
@@ -61,6 +62,7 @@ constexpr uint32_t kFineCap = 28672;     // LDS staging entries of pass 2 (112 K
 __global__ void __launch_bounds__(kSortThreads)
 coarse_hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t fb, uint32_t nhi, uint32_t chunk,
                    uint32_t* __restrict__ coarse_cnt /* [W][Q][nhi] */) {
+  __builtin_amdgcn_s_setprio(3);   // shares SIMDs with the accumulate grid, whose straight-line code would starve it of issue slots
   extern __shared__ uint32_t lds_u32[];
   const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
   for (uint32_t i = threadIdx.x; i < nhi; i += blockDim.x) lds_u32[i] = 0;
@@ -82,6 +84,7 @@ coarse_hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t fb,
 __global__ void __launch_bounds__(1024)
 coarse_prefix_kernel(uint32_t* __restrict__ coarse_cnt, uint32_t Q, uint32_t nhi,
                      uint32_t* __restrict__ region_start) {
+  __builtin_amdgcn_s_setprio(3);   // shares SIMDs with the accumulate grid, whose straight-line code would starve it of issue slots
   __shared__ uint32_t scratch[17];
   const uint32_t w = blockIdx.x, hi = threadIdx.x;
   uint32_t* cw = coarse_cnt + (size_t)w * Q * nhi;
@@ -109,6 +112,7 @@ __global__ void __launch_bounds__(kSortThreads)
 coarse_scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t hb, uint32_t fb, uint32_t chunk,
                       const uint32_t* __restrict__ coarse_base /* [W][Q][nhi] */, uint32_t* __restrict__ tmp_idx,
                       uint16_t* __restrict__ tmp_fine) {
+  __builtin_amdgcn_s_setprio(3);   // shares SIMDs with the accumulate grid, whose straight-line code would starve it of issue slots
   extern __shared__ uint32_t lds_u32[];   // [nhi] region cursors
   const uint32_t nhi = 1u << hb;
   const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
@@ -134,10 +138,13 @@ coarse_scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t 
 }
 
 // grid = (nhi, W), block = 1024, dynamic LDS = (kFineCap + 2 * nfine + 32) * 4 bytes.
+// Loops are kept rolled (<= 32 VGPRs): the 4 waves/SIMD of a 1024-thread workgroup must fit into the 128
+// VGPRs that two resident accumulate waves leave free on a SIMD, or the workgroup waits for the accumulate tail.
 __global__ void __launch_bounds__(kSortThreads)
 fine_sort_kernel(const uint32_t* __restrict__ tmp_idx, const uint16_t* __restrict__ tmp_fine, uint32_t n,
                  uint32_t lb, uint32_t fb, const uint32_t* __restrict__ region_start,
                  uint32_t* __restrict__ sorted, uint32_t* __restrict__ bucket_size) {
+  __builtin_amdgcn_s_setprio(3);   // shares SIMDs with the accumulate grid, whose straight-line code would starve it of issue slots
   extern __shared__ uint32_t lds_u32[];
   const uint32_t nfine = 1u << fb;
   const uint32_t nhi = gridDim.x;
@@ -153,6 +160,7 @@ fine_sort_kernel(const uint32_t* __restrict__ tmp_idx, const uint16_t* __restric
   uint32_t* out = sorted + (size_t)w * n + rs;
   for (uint32_t i = threadIdx.x; i < nfine; i += blockDim.x) bins[i] = 0;
   __syncthreads();
+#pragma unroll 1
   for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) atomicAdd(&bins[tf[i]], 1u);
   __syncthreads();
   // exclusive scan of the fine histogram (nfine <= 1024: one bin per thread)
@@ -166,14 +174,17 @@ fine_sort_kernel(const uint32_t* __restrict__ tmp_idx, const uint16_t* __restric
   }
   __syncthreads();
   if (size <= kFineCap) {
-    for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) {
+  #pragma unroll 1
+  for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) {
       const uint32_t pos = atomicAdd(&bins[tf[i]], 1u);
       staging[pos] = ti[i];
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) out[i] = staging[i];
+  #pragma unroll 1
+  for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) out[i] = staging[i];
   } else {
-    for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) {
+  #pragma unroll 1
+  for (uint32_t i = threadIdx.x; i < size; i += blockDim.x) {
       const uint32_t pos = atomicAdd(&bins[tf[i]], 1u);
       out[pos] = ti[i];
     }
@@ -192,12 +203,14 @@ __device__ __forceinline__ uint32_t window_scan_lds(uint32_t* tot, uint32_t* scr
   const uint32_t per = (nb + blockDim.x - 1) / blockDim.x;   // consecutive entries per thread
   const uint32_t first = threadIdx.x * per;
   uint32_t local = 0;
+#pragma unroll 1
   for (uint32_t j = 0; j < per; ++j) {
     const uint32_t d = first + j;
     if (d < nb) local += tot[d + (d >> 5)];
   }
   uint32_t total;
   uint32_t run = block_exclusive_scan(local, scratch, &total);
+#pragma unroll 1
   for (uint32_t j = 0; j < per; ++j) {
     const uint32_t d = first + j;
     if (d < nb) {
@@ -214,20 +227,25 @@ __global__ void __launch_bounds__(kSortThreads)
 plan_kernel(const uint32_t* __restrict__ bucket_size, uint32_t lb, uint32_t CH,
             uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ item_start,
             uint32_t* __restrict__ win_items) {
+  __builtin_amdgcn_s_setprio(3);   // shares SIMDs with the accumulate grid, whose straight-line code would starve it of issue slots
   extern __shared__ uint32_t lds_u32[];
   const uint32_t nb = 1u << lb;
   const uint32_t w = blockIdx.x;
   uint32_t* tot = lds_u32;                               // skewed: index i lives at i + (i >> 5)
   uint32_t* scratch = lds_u32 + nb + (nb >> 5) + 1;      // 17 words
   const uint32_t* bsz = bucket_size + (size_t)w * nb;
+#pragma unroll 1
   for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) tot[d + (d >> 5)] = bsz[d];
   __syncthreads();
   window_scan_lds(tot, scratch, nb);
+#pragma unroll 1
   for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) bucket_start[(size_t)w * nb + d] = tot[d + (d >> 5)];
   __syncthreads();
+#pragma unroll 1
   for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) tot[d + (d >> 5)] = (bsz[d] + CH - 1) / CH;
   __syncthreads();
   const uint32_t total_items = window_scan_lds(tot, scratch, nb);
+#pragma unroll 1
   for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) item_start[(size_t)w * nb + d] = tot[d + (d >> 5)];
   if (threadIdx.x == 0) win_items[w] = total_items;
 }
@@ -253,6 +271,7 @@ __device__ __forceinline__ void bucket_items(uint32_t s, uint32_t CH, uint32_t* 
 __global__ void __launch_bounds__(kSizeThreads)
 size_hist_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_buckets, uint32_t CH,
                  uint32_t* __restrict__ wg_bins /* [CH + 1 rows, row r = size class CH - r][gridDim.x] */) {
+  __builtin_amdgcn_s_setprio(3);   // shares SIMDs with the accumulate grid, whose straight-line code would starve it of issue slots
   extern __shared__ uint32_t lds_u32[];
   for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x) lds_u32[i] = 0;
   __syncthreads();
@@ -274,6 +293,7 @@ size_hist_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_bucket
 __global__ void __launch_bounds__(1024)
 size_scan_kernel(uint32_t* __restrict__ wg_bins, uint32_t table_len, uint32_t* __restrict__ win_items, uint32_t W,
                  PlanCounters* __restrict__ counters) {
+  __builtin_amdgcn_s_setprio(3);   // shares SIMDs with the accumulate grid, whose straight-line code would starve it of issue slots
   __shared__ uint32_t scratch[17];
   const uint32_t t = threadIdx.x;
   const uint32_t per = (table_len + blockDim.x - 1) / blockDim.x;
@@ -305,6 +325,7 @@ __global__ void __launch_bounds__(kSizeThreads)
 size_scatter_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_buckets, uint32_t CH,
                     const uint32_t* __restrict__ wg_base, uint2* __restrict__ order,
                     uint32_t* __restrict__ multi_list, PlanCounters* __restrict__ counters) {
+  __builtin_amdgcn_s_setprio(3);   // shares SIMDs with the accumulate grid, whose straight-line code would starve it of issue slots
   extern __shared__ uint32_t lds_u32[];
   uint32_t* cnt = lds_u32;              // [CH + 1] local ranks
   uint32_t* base = lds_u32 + CH + 1;    // [CH + 1] first position of this workgroup per size class
