@@ -158,6 +158,10 @@ Plan make_plan(size_t n, uint32_t c) {
   // coarse regions of ~16 k points so that pass 2 sorts a region inside LDS; at least 2 fine bits
   uint32_t hb = 0;
   while (hb + 2 < p.lb && hb < 10 && (n >> hb) > 16384) ++hb;
+  if (const char* e = std::getenv("MSM_AMD_HB")) {   // experiments: coarse bits of the two-pass sort
+    const int v = std::atoi(e);
+    if (v >= 0 && (uint32_t)v + 2 <= p.lb) hb = (uint32_t)v;
+  }
   p.hb = hb;
   p.fb = p.lb - hb;
   if (p.fb > 10) {   // the fine histogram is scanned with one bin per thread (<= 1024 bins)

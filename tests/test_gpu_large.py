@@ -80,3 +80,43 @@ def test_digit_carry_chains(cfg):
         finally:
             cfg.set_window_size(0)
         assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(co.msm_best(sb, pb, n, 2))
+
+
+def test_all_bases_equal_and_small_scalars(cfg):
+    """SURVEY §8(d) secondary distributions: every base the same point (each bucket is a chain of P + P doublings
+    and equal-point additions) and scalars below 2^16 (only the two lowest windows are populated)."""
+    n = 1 << 14
+    pb1, sb = co.gen_instance(o.SEED_BASE + 8, n)
+    same = pb1[:64] * n
+    out = cfg.msm(sb, same, n)
+    assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(co.msm_best(sb, same, n))
+    rng = random.Random(16)
+    small = b"".join(o.encode_scalar_h2c(rng.randrange(1 << 16)) for _ in range(n))
+    out = cfg.msm(small, pb1, n)
+    assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(co.msm_best(small, pb1, n))
+
+
+def test_log20_linearity(cfg):
+    """Size-independent property at the headline size: MSM(k1 + k2, P) == MSM(k1, P) + MSM(k2, P), with the
+    final addition done by the oracle's group law."""
+    n = 1 << 20
+    dp, ds1 = cfg.generate_instance(o.SEED_BASE + 31, n, False)      # canonical little-endian scalars
+    dq, ds2 = cfg.generate_instance(o.SEED_BASE + 32, n, False)
+    try:
+        import numpy as np
+        k1 = np.frombuffer(cfg.to_host(ds1, 32 * n), dtype="<u8").reshape(n, 4)
+        k2 = np.frombuffer(cfg.to_host(ds2, 32 * n), dtype="<u8").reshape(n, 4)
+        r = o.R_ORDER
+        s = bytearray(32 * n)
+        for i in range(n):   # 256-bit modular addition on the host (Python integers)
+            a = int.from_bytes(k1[i].tobytes(), "little") + int.from_bytes(k2[i].tobytes(), "little")
+            s[32 * i:32 * i + 32] = (a - r if a >= r else a).to_bytes(32, "little")
+        d_sum = cfg.alloc(32 * n)
+        cfg.to_device(d_sum, bytes(s))
+        outs = cfg.msm_batch_device([ds1, ds2, d_sum], [dp, dp, dp], [n, n, n], scalar_layout=1)   # SCALAR_CANON_LE
+        cfg.free(d_sum)
+        a, b, c = (o.decode_jacobian_mont_le(x) for x in outs)
+        assert o.aff_add(a, b) == c
+    finally:
+        for d in (dp, ds1, dq, ds2):
+            cfg.free(d)
