@@ -155,9 +155,11 @@ Plan make_plan(size_t n, uint32_t c) {
   Q = std::max(1u, std::min(Q, max_q));
   p.Q = Q;
   p.chunk = (uint32_t)((((n + Q - 1) / Q) + 63) & ~(size_t)63);
-  // coarse regions of ~16 k points so that pass 2 sorts a region inside LDS; at least 2 fine bits
+  // coarse regions of ~16 k points so that pass 2 sorts a region inside LDS; at least 2 fine bits.  At most 128
+  // regions: beyond that pass 1 keeps too many partially written lines open (2^24 points: 10.2 ms with 1024
+  // regions, 6.0 ms with 128, whose 131 k-point regions pass 2 scatters directly inside an L2-sized range).
   uint32_t hb = 0;
-  while (hb + 2 < p.lb && hb < 10 && (n >> hb) > 16384) ++hb;
+  while (hb + 2 < p.lb && hb < 7 && (n >> hb) > 16384) ++hb;
   if (const char* e = std::getenv("MSM_AMD_HB")) {   // experiments: coarse bits of the two-pass sort
     const int v = std::atoi(e);
     if (v >= 0 && (uint32_t)v + 2 <= p.lb) hb = (uint32_t)v;
