@@ -157,6 +157,13 @@ int msm_amd_bases_prepare_device(msm_amd_ctx* ctx, int point_layout, const void*
 int msm_amd_msm_prepared(msm_amd_ctx* ctx, int scalar_layout, const void* scalars, const void* d_prepared, size_t n,
                          void* out96);
 
+/* ---- partial results ------------------------------------------------------------------------
+ * Host-side sum of `count` results (96 B Jacobian Montgomery LE each, as every entry point above returns
+ * them), normalised like them.  It is the final addition of gpu_with_cpu (msm.rs:418-419) made available to
+ * callers that split ONE instance by point range across several GPUs: every rank runs the MSM of its range,
+ * the 96-byte partial results are all-gathered, and every rank adds them. */
+int msm_amd_sum_points(const void* points96, size_t count, void* out96);
+
 /* ---- device memory helpers (so callers without a HIP binding can stage data) ------------------ */
 int msm_amd_device_alloc(msm_amd_ctx* ctx, size_t bytes, void** d_ptr);
 int msm_amd_device_free(msm_amd_ctx* ctx, void* d_ptr);

@@ -44,7 +44,7 @@ EXPORTS = [
     "msm_amd_instances_save", "msm_amd_instances_open", "msm_amd_instances_count", "msm_amd_instances_size",
     "msm_amd_instances_read", "msm_amd_instances_close", "msm_amd_instances_default_path", "msm_amd_to_wire",
     "msm_amd_from_wire", "msm_amd_sort_pairs_device", "msm_amd_bases_upload", "msm_amd_bases_prepare_device",
-    "msm_amd_msm_prepared",
+    "msm_amd_msm_prepared", "msm_amd_sum_points",
 ]
 
 
@@ -81,6 +81,7 @@ def _lib():
         L.msm_amd_bases_upload.argtypes = [c_void_p, c_int, c_void_p, c_size_t, POINTER(c_void_p)]
         L.msm_amd_bases_prepare_device.argtypes = [c_void_p, c_int, c_void_p, c_size_t, c_void_p]
         L.msm_amd_msm_prepared.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.msm_amd_sum_points.argtypes = [c_void_p, c_size_t, c_void_p]
         L.msm_amd_sort_pairs_device.argtypes = [c_void_p, c_void_p, c_size_t, c_uint32, POINTER(c_float)]
         L.msm_amd_instances_save.argtypes = [c_char_p, c_size_t, POINTER(c_size_t), POINTER(c_void_p),
                                              POINTER(c_void_p)]
@@ -327,6 +328,18 @@ def test_op_host(op, a, b, count):
     if st != OK:
         raise MsmError(st)
     return list(out)
+
+
+def sum_points(results) -> bytes:
+    """Host sum of 96-byte results (the final addition of gpu_with_cpu, msm.rs:418-419)."""
+    blob = b"".join(results)
+    if len(blob) != 96 * len(results):
+        raise ValueError("every result must be 96 bytes")
+    out = ctypes.create_string_buffer(96)
+    st = _lib().msm_amd_sum_points(blob, len(results), out)
+    if st != OK:
+        raise MsmError(st)
+    return out.raw
 
 
 def final_accumulation(res_be32, num_windows, window_size):

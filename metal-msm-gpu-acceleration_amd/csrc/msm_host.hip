@@ -1180,6 +1180,19 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   return MSM_AMD_OK;
 }
 
+int msm_amd_sum_points(const void* points96, size_t count, void* out96) {
+  if ((!points96 && count) || !out96) return MSM_AMD_INPUT_ERROR;
+  Jacobian acc = jac_identity();
+  for (size_t i = 0; i < count; ++i) {
+    Jacobian p;
+    std::memcpy(&p, (const uint8_t*)points96 + i * 96, 96);
+    acc = jac_add(acc, p);
+  }
+  const Jacobian res = normalise(acc);
+  std::memcpy(out96, &res, 96);
+  return MSM_AMD_OK;
+}
+
 int msm_amd_final_accumulation(const uint32_t* res_be32, uint32_t num_windows, uint32_t window_size,
                                uint32_t* point_out) {
   if (!res_be32 || !point_out || num_windows == 0) return MSM_AMD_INPUT_ERROR;

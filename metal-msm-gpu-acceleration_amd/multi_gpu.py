@@ -1,4 +1,5 @@
-"""Instance sharding across the GPUs of one node.
+"""Sharding across the GPUs of one node: independent instances by rank (the headline
+configuration), or ONE huge instance by point range (`point_range`, `sharded_msm`).
 
 MSM instances are independent (the reference loops over them: gpu_profiler.rs:104-106,
 benches/msm_benchmark.rs:29-34), so rank r simply owns a contiguous block of instances and there is NO
@@ -74,3 +75,25 @@ class ResultGatherer:
     def fetch(self):
         raw = bytes(self.all.cpu().numpy().tobytes())
         return [raw[i * RESULT_BYTES:(i + 1) * RESULT_BYTES] for i in range(self.world * self.per_rank)]
+
+
+def point_range(rank: int, world: int, n: int):
+    """[begin, end) of the points rank `rank` owns when ONE instance of n points is split across `world` GPUs
+    (the same algebra as the reference's GPU + CPU split by point range, msm.rs:385-419)."""
+    if not (0 <= rank < world) or n < 0:
+        raise ValueError("bad rank/world/n")
+    base, extra = divmod(n, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def sharded_msm(local_msm, sum_points, rank: int, world: int, n: int, dist=None, device=None):
+    """One MSM over n points on `world` GPUs.  `local_msm(begin, end)` returns this rank's 96-byte partial result
+    for its point range (e.g. `lambda b, e: cfg.msm_batch_device([ds + 32 * b], [dp + 64 * b], [e - b])[0]`);
+    the partials are all-gathered (world x 96 bytes over RCCL: latency only, a point addition is not a reduce-op)
+    and every rank adds them with `sum_points` (`msm_amd_sum_points`).  Ranks with an empty range contribute the
+    identity (z = 0)."""
+    begin, end = point_range(rank, world, n)
+    partial = local_msm(begin, end) if end > begin else bytes(RESULT_BYTES)
+    partials = all_gather_results([partial], dist, device)
+    return sum_points(partials)

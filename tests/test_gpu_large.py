@@ -120,3 +120,22 @@ def test_log20_linearity(cfg):
     finally:
         for d in (dp, ds1, dq, ds2):
             cfg.free(d)
+
+
+def test_point_range_split_on_one_gpu(cfg, msm_pkg):
+    """The single-instance split of SURVEY §8e, all ranges on this GPU: partial MSMs over 3 point ranges of a
+    2^16 instance, added by msm_amd_sum_points, equal the whole MSM."""
+    import importlib
+    mg = importlib.import_module("metal-msm-gpu-acceleration_amd.multi_gpu")
+    n = 1 << 16
+    dp, ds = cfg.generate_instance(o.SEED_BASE + 41, n, True)
+    try:
+        whole = cfg.msm_batch_device([ds], [dp], [n])[0]
+        world = 3
+        local = lambda b, e: cfg.msm_batch_device([ds + 32 * b], [dp + 64 * b], [e - b])[0]
+        parts = [local(*mg.point_range(r, world, n)) for r in range(world)]
+        assert msm_pkg.sum_points(parts) == whole
+        assert mg.sharded_msm(local, msm_pkg.sum_points, 0, 1, n) == whole
+    finally:
+        cfg.free(dp)
+        cfg.free(ds)
