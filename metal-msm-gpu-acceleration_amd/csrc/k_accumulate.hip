@@ -6,8 +6,7 @@
 namespace msm_amd {
 
 // One lane per work item.  A work item is (bucket b, chunk j): points [j*CH, min(size, (j+1)*CH)) of the
-// bucket's slice of `sorted`.  The lane gathers each 80-byte internal-form affine base (software-prefetched
-// one point ahead) and performs a mixed XYZZ+affine addition on 29-bit limbs (pti_madd, madd-2008-s, 8M+2S).  Items arrive sorted by
+// bucket's slice of `sorted`.  The lane gathers each 64-byte packed affine base and performs a mixed XYZZ+affine addition on 29-bit limbs (pti_madd, madd-2008-s, 8M+2S).  Items arrive sorted by
 // descending length (`order`), so the 64 lanes of a wave run the same number of iterations and the
 // longest items start first.  Replaces kernel bucket_wise_accumulation (msm.h.metal:75-315), which
 // splits pairs evenly over threads and merges bucket boundaries through threadgroup memory.
@@ -36,15 +35,33 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
   const uint32_t cnt = min(size - lo, CH);
   const uint32_t* idx = sorted + (size_t)w * n + bucket_start[b] + lo;
   PtI acc = pti_identity();
-  uint32_t next_idx = idx[0];
+  // Software pipeline.  LOW_OCC (2 waves/SIMD) has ~20 spare VGPRs: the packed 64-byte record of point i + 1 is
+  // gathered while point i is added, so a whole mixed addition (~5 us) hides the gather.  The 3-wave variant has
+  // no registers to spare: it issues the gather at the top of the iteration and first consumes it after the
+  // Z1^2 squaring inside pti_madd, prefetching only the next index.
+  uint32_t cur_idx = idx[0];
+  uint32_t next_idx = cnt > 1 ? idx[1] : 0u;
+  AffPacked pre;
+  if (LOW_OCC) {
+    pre.x = load_u256(&bases[cur_idx & 0x7FFFFFFFu].x);
+    pre.y = load_u256(&bases[cur_idx & 0x7FFFFFFFu].y);
+  }
 #pragma unroll 1
   for (uint32_t i = 0; i < cnt; ++i) {
-    // the gather of this point is issued here and first consumed after the Z1^2 squaring inside pti_madd,
-    // which hides most of its latency; only the next index is prefetched (one register, not a whole point)
-    AffI cur = load_affi(&bases[next_idx & 0x7FFFFFFFu]);
+    AffI cur;
+    if (LOW_OCC) {
+      cur = affi_unpack(pre);
+      if (i + 1 < cnt) {
+        pre.x = load_u256(&bases[next_idx & 0x7FFFFFFFu].x);
+        pre.y = load_u256(&bases[next_idx & 0x7FFFFFFFu].y);
+      }
+    } else {
+      cur = load_affi(&bases[cur_idx & 0x7FFFFFFFu]);
+    }
     const bool cur_is_id = affi_is_identity(cur);
-    const bool negate = (next_idx >> 31) != 0;   // negative digit: add -P (signed digits, see digits_kernel)
-    if (i + 1 < cnt) next_idx = idx[i + 1];
+    const bool negate = (cur_idx >> 31) != 0;   // negative digit: add -P (signed digits, see digits_kernel)
+    cur_idx = next_idx;
+    if (i + 2 < cnt) next_idx = idx[i + 2];
     {
       const fe29 ny = Fq29::neg(cur.y);
 #pragma unroll
@@ -123,10 +140,13 @@ combine_big_kernel(const uint32_t* __restrict__ big_list, const PlanCounters* __
   }
 }
 
-void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
-                       PtI* partials, bool low_occupancy, hipEvent_t before_kernel, hipEvent_t after_kernel) {
+void launch_clear_buckets(hipStream_t st, const Plan& p, PtI* buckets) {
   // empty buckets produce no work item: all-zero memory is the identity (Z = 0)
   (void)hipMemsetAsync(buckets, 0, p.total_buckets * sizeof(PtI), st);
+}
+
+void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
+                       PtI* partials, bool low_occupancy, hipEvent_t before_kernel, hipEvent_t after_kernel) {
   if (before_kernel) (void)hipEventRecord(before_kernel, st);
   if (low_occupancy) {
     hipLaunchKernelGGL(accumulate_kernel<true>, dim3((unsigned)((p.max_items + 63) / 64)), dim3(64), 0, st, bases,

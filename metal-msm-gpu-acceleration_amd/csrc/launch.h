@@ -57,6 +57,7 @@ void launch_be32_to_le(hipStream_t st, const uint32_t* in, size_t words, uint32_
 void launch_ark_affine_to_affine(hipStream_t st, const uint8_t* in, uint32_t n, Affine* out);
 
 // k_accumulate.hip
+void launch_clear_buckets(hipStream_t st, const Plan& p, PtI* buckets);   // must precede launch_accumulate
 void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
                        PtI* partials, bool low_occupancy, hipEvent_t before_kernel, hipEvent_t after_kernel);
 

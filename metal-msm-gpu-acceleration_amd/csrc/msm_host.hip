@@ -441,6 +441,9 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_DIGITS], fs));
   launch_sort(fs, p, sb);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_SORT], fs));
+  // the bucket matrix is cleared on the front stream too (its last reader, the reduction of the previous user of
+  // this workspace, was waited for above), so the main stream goes from one accumulate straight to the next
+  launch_clear_buckets(fs, p, (PtI*)w.buckets.p);
   if (fs != st) {
     HIP_TRY(ctx, hipEventRecord(w.front_done, fs));
     HIP_TRY(ctx, hipStreamWaitEvent(st, w.front_done, 0));
