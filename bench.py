@@ -21,8 +21,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-size", type=int, default=20)
     ap.add_argument("--instances", type=int, default=5, help="instances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
