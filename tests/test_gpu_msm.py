@@ -177,3 +177,58 @@ def test_persistent_bases_match_the_per_call_path(cfg, msm_pkg):
         for h in handles:
             cfg.free(h)
         cfg.free(d_raw)
+
+
+def test_pipelined_submit_wait_and_ticket_errors(cfg, msm_pkg):
+    """submit_batch_device / wait_batch: several batches in flight give the same bytes as blocking calls, in any
+    collection order; a fifth batch, a stale ticket and a bogus ticket are refused with INPUT_ERROR."""
+    n = 3000
+    insts = []
+    for j in range(4):
+        dp, ds = cfg.generate_instance(o.SEED_BASE + 600 + j, n, True)
+        insts.append((dp, ds))
+    try:
+        want = [cfg.msm_batch_device([ds], [dp], [n])[0] for dp, ds in insts]
+        handles = [cfg.submit_batch_device([ds, ds], [dp, dp], [n, n - 7]) for dp, ds in insts]   # 4 batches of 2
+        with pytest.raises(msm_pkg.MsmError) as e:
+            cfg.submit_batch_device([insts[0][1]], [insts[0][0]], [n])                             # no free slot
+        assert e.value.status == msm_pkg.INPUT_ERROR
+        for j in (2, 0, 3, 1):
+            got = cfg.wait_batch(handles[j])
+            assert got[0] == want[j]
+            assert got[1] == cfg.msm_batch_device([insts[j][1]], [insts[j][0]], [n - 7])[0]
+        with pytest.raises(msm_pkg.MsmError) as e:
+            cfg.wait_batch(handles[1])                                                             # already collected
+        assert e.value.status == msm_pkg.INPUT_ERROR
+        with pytest.raises(msm_pkg.MsmError):
+            cfg.wait_batch((99, handles[0][1], 1))
+    finally:
+        for dp, ds in insts:
+            cfg.free(dp)
+            cfg.free(ds)
+
+
+def test_one_ctx_from_two_threads(cfg, msm_pkg):
+    """Calls on one ctx are serialised internally (the reference takes a process-wide mutex, msm.rs:248-255):
+    two host threads hammering the same ctx get the right, identical answers."""
+    import threading
+    pts, sc = small_instance(777, 900)
+    sb, pb = h2c_instance_bytes(pts, sc)
+    want = msm_pkg.gpu_msm_h2c(sb, pb, cfg)
+    assert o.decode_jacobian_mont_le(want) == _expect(pts, sc)
+    results, errors = [], []
+
+    def work():
+        try:
+            for _ in range(10):
+                results.append(msm_pkg.gpu_msm_h2c(sb, pb, cfg))
+        except Exception as ex:   # noqa: BLE001 - surfaced below
+            errors.append(ex)
+
+    ts = [threading.Thread(target=work) for _ in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors
+    assert len(results) == 20 and all(r == want for r in results)
