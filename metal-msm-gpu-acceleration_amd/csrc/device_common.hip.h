@@ -1,29 +1,44 @@
 // Pippenger MSM pipeline for BN254 G1 on gfx950 (MI355X): overview + helpers shared by the kernel TUs
 // (k_sort.hip, k_accumulate.hip, k_reduce.hip, k_misc.hip, k_stage.hip) and by the host driver.
 //
-// Pipeline (one MSM of n points, window c bits, W = ceil(254/c) windows, nb = 2^c digit values):
+// Pipeline (one MSM of n points, window c bits, W = floor(254/c) + 1 windows of SIGNED digits, nb = 2^(c-1)
+// slots per window; slot i holds the points whose digit magnitude is i + 1):
 //
-//   digits_kernel        scalars (32 B, Montgomery or canonical)  -> digits[W][n] (u16, SoA)
-//   hist_kernel          digits -> counts[W][Q][nb]     LDS histogram per (chunk q, window w)
-//   chunk_prefix_kernel  counts -> bucket_size[W][nb], counts := exclusive prefix over chunks
-//   scan_kernel          bucket_size -> bucket_start[W][nb]  (per-window exclusive scan in LDS)
-//   scatter_kernel       digits + cursors -> sorted[W][n]  (point indices grouped by digit)
-//   convert_bases_kernel bases (affine 64 B, external Montgomery R=2^256) -> bases29 (64 B, internal domain rho=2^261)
-//   accumulate_kernel    sorted + bases29 -> buckets[W][nb]  (XYZZ 144 B internal)         <- dominant
-//   reduce_seg_kernel    buckets -> S[W][nseg], T[W][nseg]   (segments of 8 buckets)
-//   reduce_tree_kernel   S, T -> partial[W][K+1]  (one plain sum + K bit-subset sums per window)
-//   host                 Horner over bit positions of the (K+1)*W partial points
+//   front stream (k_sort.hip, k_misc.hip)
+//   convert_bases_kernel  bases (affine 64 B, Montgomery R = 2^256) -> bases29 (64 B packed, internal domain 2^261)
+//   digits_kernel         scalars (32 B, Montgomery or canonical) -> digits[W][n] (u16 = sign << 15 | magnitude)
+//   coarse_hist_kernel    digits -> coarse_cnt[W][Q][2^hb]   LDS histogram of the high slot bits per (chunk, window)
+//   coarse_prefix_kernel  coarse_cnt -> region_start[W][2^hb + 1], coarse_cnt := first position per (chunk, region)
+//   coarse_scatter_kernel digits -> tmp_idx / tmp_fine, grouped by coarse region (per-workgroup LDS cursors)
+//   fine_sort_kernel      one region per workgroup, counting sort by the low slot bits inside LDS
+//                         -> sorted[W][n] (point index | sign << 31), bucket_size[W][nb]
+//   plan_kernel           bucket_size -> bucket_start, item_start (work items of <= CH points), win_items
+//   size_hist/scan/scatter  work items counting-sorted by descending length -> order[], list of split buckets
+//
+//   main stream (k_accumulate.hip)
+//   accumulate_kernel     one lane per work item: sorted + bases29 -> buckets[W][nb] (XYZZ, 144 B) or
+//                         item_partials for split buckets                                      <- dominant
+//
+//   reduce stream (k_accumulate.hip, k_reduce.hip)
+//   combine_small/big     sum the partials of split buckets into buckets
+//   reduce_seg_kernel     buckets -> S[W][nseg], T[W][nseg]   (running sums over segments of 8 slots)
+//   reduce_tree_kernel    S, T -> partial[W][K+2]  (plain sums + K bit-subset sums per window, external Jacobian)
+//   host                  Horner over the bit positions of the (K+2) * W partial points (msm_host.hip host_combine)
 //
 // This replaces the reference's prepare_buckets_indices / sort_buckets (CPU rayon sort!) /
 // bucket_wise_accumulation / sum_reduction_partial+final kernels (src/metal/shader/msm.h.metal:17-562,
-// src/metal/msm/sort_buckets.rs:15-34) with a design derived for wave64 + 160 KB LDS:
-//   * the sort is a per-window counting sort whose whole digit histogram (2^15 x u32 = 128 KB) lives in
-//     LDS, so ranking is LDS atomics and the only global traffic is digits in / indices out;
+// src/metal/msm/sort_buckets.rs:15-34) with a design derived for wave64 + 160 KB LDS + eight non-coherent L2s:
+//   * the sort is a two-pass MSD counting sort per window: pass 1 keeps every workgroup's stores on a few
+//     open lines, pass 2 sorts a region inside LDS, so both passes write about their payload (a one-pass
+//     scatter of 4-byte indices wrote 8x its payload as partial-line evictions);
 //   * sorted output is 4 B point indices plus per-bucket offsets (the reference sorts 8 B pairs and
 //     then binary-searches bucket boundaries per threadgroup, msm.h.metal:61-73,130-131);
-//   * window sums use running sums over 8-bucket segments followed by bit-subset tree sums, which
+//   * work is balanced by ordering work items by length, not by splitting pairs evenly over threads and
+//     merging bucket boundaries through threadgroup memory (msm.h.metal:229-314);
+//   * window sums use running sums over 8-slot segments followed by bit-subset tree sums, which
 //     needs no scalar multiplications (the reference multiplies sums by counts with double-and-add in
-//     every combine, msm.h.metal:429-430).
+//     every combine, msm.h.metal:429-430);
+//   * the three streams work on three different instances at any time (msm_host.hip enqueue_msm).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bn254_ec29.hip.h"

@@ -33,11 +33,11 @@ gen_instance_kernel(uint64_t seed, uint32_t n, int scalars_mont, Affine* __restr
 }
 
 
-// External affine bases (64 B, 8 x u32 Montgomery R = 2^256) -> internal 29-bit-limb form (80 B).  One pass
+// External affine bases (64 B, 8 x u32 Montgomery R = 2^256) -> packed internal form (64 B, see bn254_ec29.hip.h).  One pass
 // per MSM: 2 internal multiplications per point, ~1 % of the accumulation work.
 __global__ void __launch_bounds__(128)
 convert_bases_kernel(const Affine* __restrict__ in, uint32_t n, AffPacked* __restrict__ out) {
-  __builtin_amdgcn_s_setprio(3);   // shares SIMDs with the accumulate grid, whose straight-line code would starve it of issue slots
+  __builtin_amdgcn_s_setprio(3);   // see kFrontPriority note in launch.h
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   store_affi(&out[t], affi_from_ext(load_affine(&in[t])));

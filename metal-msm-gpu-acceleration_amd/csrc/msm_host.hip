@@ -415,10 +415,11 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   sb.multi_list = (uint32_t*)w.multi_list.p;
   sb.counters = (PlanCounters*)w.counters.p;
 
-  // Three streams, two workspaces (instance i uses workspace i % 2):
-  //   front  : conversion, digits, sort, planning of instance i      -- may run while instance i-1 accumulates
-  //   main   : accumulate + combine of instance i                    -- needs front(i) and reduce(i-2)
-  //   reduce : window reduction + copy of instance i                 -- needs main(i)
+  // Three streams, kWorkspaces workspaces (consecutive instances take consecutive workspaces):
+  //   front  : conversion, digits, sort, planning, bucket clear of instance i -- needs the workspace's previous
+  //            accumulate and reduction done; runs while instance i-1 accumulates and i-2 reduces
+  //   main   : accumulate of instance i                                      -- needs front(i)
+  //   reduce : combine + window reduction + copy of instance i               -- needs main(i)
   hipStream_t fs = ctx->overlap_front ? ctx->front_stream : st;
   hipStream_t rs = ctx->overlap_reduce ? ctx->reduce_stream : st;
   if (w.acc_pending && fs != st) {   // the previous accumulate in this workspace still reads its plan ...
