@@ -37,7 +37,7 @@ gen_instance_kernel(uint64_t seed, uint32_t n, int scalars_mont, Affine* __restr
 // per MSM: 2 internal multiplications per point, ~1 % of the accumulation work.
 __global__ void __launch_bounds__(128)
 convert_bases_kernel(const Affine* __restrict__ in, uint32_t n, AffPacked* __restrict__ out) {
-  __builtin_amdgcn_s_setprio(3);   // see kFrontPriority note in launch.h
+  __builtin_amdgcn_s_setprio(kFrontPriority);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   store_affi(&out[t], affi_from_ext(load_affine(&in[t])));

@@ -20,7 +20,7 @@ constexpr int kSortThreads = 1024;       // hist / plan / scatter workgroup size
 __global__ void __launch_bounds__(256)
 digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W, int scalars_mont,
               uint16_t* __restrict__ digits) {
-  __builtin_amdgcn_s_setprio(3);   // see kFrontPriority note in launch.h
+  __builtin_amdgcn_s_setprio(kFrontPriority);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   u256 k = load_u256(&scalars[t]);
@@ -62,7 +62,7 @@ constexpr uint32_t kFineCap = 28672;     // LDS staging entries of pass 2 (112 K
 __global__ void __launch_bounds__(kSortThreads)
 coarse_hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t fb, uint32_t nhi, uint32_t chunk,
                    uint32_t* __restrict__ coarse_cnt /* [W][Q][nhi] */) {
-  __builtin_amdgcn_s_setprio(3);   // see kFrontPriority note in launch.h
+  __builtin_amdgcn_s_setprio(kFrontPriority);
   extern __shared__ uint32_t lds_u32[];
   const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
   for (uint32_t i = threadIdx.x; i < nhi; i += blockDim.x) lds_u32[i] = 0;
@@ -84,7 +84,7 @@ coarse_hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t fb,
 __global__ void __launch_bounds__(1024)
 coarse_prefix_kernel(uint32_t* __restrict__ coarse_cnt, uint32_t Q, uint32_t nhi,
                      uint32_t* __restrict__ region_start) {
-  __builtin_amdgcn_s_setprio(3);   // see kFrontPriority note in launch.h
+  __builtin_amdgcn_s_setprio(kFrontPriority);
   __shared__ uint32_t scratch[17];
   const uint32_t w = blockIdx.x, hi = threadIdx.x;
   uint32_t* cw = coarse_cnt + (size_t)w * Q * nhi;
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(kSortThreads)
 coarse_scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t hb, uint32_t fb, uint32_t chunk,
                       const uint32_t* __restrict__ coarse_base /* [W][Q][nhi] */, uint32_t* __restrict__ tmp_idx,
                       uint16_t* __restrict__ tmp_fine) {
-  __builtin_amdgcn_s_setprio(3);   // see kFrontPriority note in launch.h
+  __builtin_amdgcn_s_setprio(kFrontPriority);
   extern __shared__ uint32_t lds_u32[];   // [nhi] region cursors
   const uint32_t nhi = 1u << hb;
   const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(kSortThreads)
 fine_sort_kernel(const uint32_t* __restrict__ tmp_idx, const uint16_t* __restrict__ tmp_fine, uint32_t n,
                  uint32_t lb, uint32_t fb, const uint32_t* __restrict__ region_start,
                  uint32_t* __restrict__ sorted, uint32_t* __restrict__ bucket_size) {
-  __builtin_amdgcn_s_setprio(3);   // see kFrontPriority note in launch.h
+  __builtin_amdgcn_s_setprio(kFrontPriority);
   extern __shared__ uint32_t lds_u32[];
   const uint32_t nfine = 1u << fb;
   const uint32_t nhi = gridDim.x;
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(kSortThreads)
 plan_kernel(const uint32_t* __restrict__ bucket_size, uint32_t lb, uint32_t CH,
             uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ item_start,
             uint32_t* __restrict__ win_items) {
-  __builtin_amdgcn_s_setprio(3);   // see kFrontPriority note in launch.h
+  __builtin_amdgcn_s_setprio(kFrontPriority);
   extern __shared__ uint32_t lds_u32[];
   const uint32_t nb = 1u << lb;
   const uint32_t w = blockIdx.x;
@@ -271,7 +271,7 @@ __device__ __forceinline__ void bucket_items(uint32_t s, uint32_t CH, uint32_t* 
 __global__ void __launch_bounds__(kSizeThreads)
 size_hist_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_buckets, uint32_t CH,
                  uint32_t* __restrict__ wg_bins /* [CH + 1 rows, row r = size class CH - r][gridDim.x] */) {
-  __builtin_amdgcn_s_setprio(3);   // see kFrontPriority note in launch.h
+  __builtin_amdgcn_s_setprio(kFrontPriority);
   extern __shared__ uint32_t lds_u32[];
   for (uint32_t i = threadIdx.x; i <= CH; i += blockDim.x) lds_u32[i] = 0;
   __syncthreads();
@@ -293,7 +293,7 @@ size_hist_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_bucket
 __global__ void __launch_bounds__(1024)
 size_scan_kernel(uint32_t* __restrict__ wg_bins, uint32_t table_len, uint32_t* __restrict__ win_items, uint32_t W,
                  PlanCounters* __restrict__ counters) {
-  __builtin_amdgcn_s_setprio(3);   // see kFrontPriority note in launch.h
+  __builtin_amdgcn_s_setprio(kFrontPriority);
   __shared__ uint32_t scratch[17];
   const uint32_t t = threadIdx.x;
   const uint32_t per = (table_len + blockDim.x - 1) / blockDim.x;
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(kSizeThreads)
 size_scatter_kernel(const uint32_t* __restrict__ bucket_size, uint32_t total_buckets, uint32_t CH,
                     const uint32_t* __restrict__ wg_base, uint2* __restrict__ order,
                     uint32_t* __restrict__ multi_list, PlanCounters* __restrict__ counters) {
-  __builtin_amdgcn_s_setprio(3);   // see kFrontPriority note in launch.h
+  __builtin_amdgcn_s_setprio(kFrontPriority);
   extern __shared__ uint32_t lds_u32[];
   uint32_t* cnt = lds_u32;              // [CH + 1] local ranks
   uint32_t* base = lds_u32 + CH + 1;    // [CH + 1] first position of this workgroup per size class

@@ -76,6 +76,8 @@ void launch_gen_instance(hipStream_t st, uint64_t seed, uint32_t n, int scalars_
 // Wave priority of the front-end kernels (s_setprio 3 at their top): they share SIMDs with the accumulate grid of
 // the previous instance, whose long straight-line VALU code starves ordinary-priority waves of issue slots
 // (tools/microbench/contention.hip: 6-40x slower; with priority 3: no slowdown).  DESIGN.md section 4.
+constexpr int kFrontPriority = 3;
+
 constexpr int kRadixItems = 16;
 constexpr int kRadixTile = 256 * kRadixItems;
 void launch_ref_prepare(hipStream_t st, const u256* scalars, uint32_t n, uint32_t c, uint32_t W, uint2* pairs);
