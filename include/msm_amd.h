@@ -269,7 +269,9 @@ enum {
   MSM_AMD_OP_EC29_MADD = 22,       /* Jacobian a + affine b on internal limbs */
   MSM_AMD_OP_EC29_ADD = 23,        /* Jacobian a + Jacobian b on internal limbs */
   MSM_AMD_OP_EC29_MADD_CHAIN = 24, /* a + 64 b: 64 chained mixed additions kept in the lazy internal form */
-  MSM_AMD_OP_EC29_ADD_CHAIN = 25   /* a + 16 b: 16 chained full additions */
+  MSM_AMD_OP_EC29_ADD_CHAIN = 25,  /* a + 16 b: 16 chained full additions */
+  MSM_AMD_OP_EC29_MMADD = 26       /* -a - 4b: affine + affine (4M + 2S start of a work item) on lazily negated
+                                      operands, then three mixed additions; a, b finite with z = one */
 };
 int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count);
 /* The same operation bodies executed on the host CPU (no GPU needed): host-logic tests. */

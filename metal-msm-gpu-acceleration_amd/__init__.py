@@ -23,7 +23,7 @@ POINT_BYTES = {POINT_H2C_AFFINE: 64, POINT_ARK_PROJECTIVE: 96, POINT_ARK_AFFINE:
 (OP_UINT_ADD, OP_UINT_SUB, OP_UINT_PROD, OP_UINT_SHL, OP_UINT_SHR, OP_FP_ADD, OP_FP_SUB, OP_FP_MUL, OP_FP_NEG,
  OP_FP_POW, OP_EC_ADD, OP_EC_MUL, OP_EC_MADD, OP_EC_DBL, OP_FP29_MUL, OP_FP29_SQR, OP_FP29_SUB_K4E30,
  OP_FP29_SUB_K8E30, OP_FP29_SUB_K8E31, OP_FP29_SUB_K16E30, OP_FP29_SUB_K16E31, OP_FP29_ROUNDTRIP, OP_EC29_MADD,
- OP_EC29_ADD, OP_EC29_MADD_CHAIN, OP_EC29_ADD_CHAIN) = range(26)
+ OP_EC29_ADD, OP_EC29_MADD_CHAIN, OP_EC29_ADD_CHAIN, OP_EC29_MMADD) = range(27)
 
 
 def op_is_point(op):

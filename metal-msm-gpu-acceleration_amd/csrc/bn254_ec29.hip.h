@@ -155,6 +155,32 @@ MSM_HD PtI pti_madd(const PtI& p, const AffI& q) {
   return r;
 }
 
+// p + q, BOTH affine, neither the identity (the second point of every work item: the accumulator was just set
+// from an affine base, ZZ = ZZZ = 1).  mmadd-2008-s: pti_madd without the four multiplications by ZZ1 / ZZZ1,
+// 4M + 2S.  (px, py) = p with px < 9.5 p, py < 6 p as in pti_madd; q.y may be a lazily negated value < 4 p.
+// The result obeys the same bounds as pti_madd's.
+MSM_HD PtI pti_mmadd(const fe29& px, const fe29& py, const AffI& q) {
+  const fe29 P = Fq29::norm(Fq29::sub<K16E30>(q.x, px));   // < 17.1 p
+  const fe29 R = Fq29::norm(Fq29::sub<K8E30>(q.y, py));    // < 12.1 p
+  if (Fq29::maybe_zero(P, 18)) {
+    if (Fq29::is_zero_exact(P)) {   // same x: either q == p (double) or q == -p (identity)
+      if (Fq29::is_zero_exact(R)) return pti_double(pti_from_affi(q));
+      return pti_identity();
+    }
+  }
+  const fe29 PP = Fq29::sqr(P);
+  const fe29 PPP = Fq29::mul(P, PP);
+  const fe29 Q = Fq29::mul(px, PP);
+  const fe29 RR = Fq29::sqr(R);
+  PtI r;
+  r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.5 p
+  const fe29 T = Fq29::norm(Fq29::sub<K16E30>(Q, r.x));                                   // < 17.2 p
+  r.y = Fq29::mul2(R, T, py, Fq29::neg(PPP));    // R*T - Y1*PPP in one reduction              // < 1.2 p
+  r.zz = PP;
+  r.zzz = PPP;
+  return r;
+}
+
 // p + q, both XYZZ, neither the identity.  add-2008-s, 12M + 2S.
 MSM_HD PtI pti_add_nz(const PtI& p, const PtI& q) {
   const fe29 U1 = Fq29::mul(p.x, q.zz);

@@ -35,6 +35,7 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
   const uint32_t cnt = min(size - lo, CH);
   const uint32_t* idx = sorted + (size_t)w * n + bucket_start[b] + lo;
   PtI acc = pti_identity();
+  bool acc_affine = false;   // acc was set from an affine base and nothing was added yet (ZZ = ZZZ = 1)
   // Software pipeline.  LOW_OCC (2 waves/SIMD) has ~20 spare VGPRs: the packed 64-byte record of point i + 1 is
   // gathered while point i is added, so a whole mixed addition (~5 us) hides the gather.  The 3-wave variant has
   // no registers to spare: it issues the gather at the top of the iteration and first consumes it after the
@@ -68,7 +69,16 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
       for (int l = 0; l < 9; ++l) cur.y.l[l] = negate ? ny.l[l] : cur.y.l[l];
     }
     if (pti_is_identity(acc)) {
-      if (!cur_is_id) acc = pti_from_affi(cur);
+      if (!cur_is_id) {
+        acc = pti_from_affi(cur);
+        acc_affine = true;
+      }
+    } else if (acc_affine) {   // second point of the item (wave-uniform in practice): affine + affine, 4M + 2S
+      const PtI sum = pti_mmadd(acc.x, acc.y, cur);
+      if (!cur_is_id) {
+        acc = sum;
+        acc_affine = false;
+      }
     } else {
       const PtI sum = pti_madd(acc, cur);
       if (!cur_is_id) acc = sum;

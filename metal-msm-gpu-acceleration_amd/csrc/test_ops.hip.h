@@ -96,11 +96,30 @@ MSM_HD void run_test_op(int op, const u256* a, const u256* b, u256* out, uint32_
     PtI acc = pti_from_ext(p);
     for (int i = 0; i < 16; ++i) acc = pti_add(acc, qi);
     r = pti_to_ext(acc);
+  } else if (op == 26) {   // the start of every work item: a (affine, z = one) + b (affine) by pti_mmadd, with both
+                           // operands lazily negated first (the bound-critical case), then 3 more mixed additions
+                           // of -b: the result is -(a + b) - 3 b = -a - 4 b
+    const Jacobian q = pb[t];
+    if (jac_is_identity(p) || jac_is_identity(q)) {
+      r = jac_is_identity(p) ? q : p;   // callers pass finite points; identities are returned unchanged
+    } else {
+      Affine pa, qa;
+      pa.x = p.x;
+      pa.y = p.y;
+      qa.x = q.x;
+      qa.y = q.y;
+      AffI pi = affi_from_ext(pa), qi = affi_from_ext(qa);
+      pi.y = Fq29::neg(pi.y);
+      qi.y = Fq29::neg(qi.y);
+      PtI acc = pti_mmadd(pi.x, pi.y, qi);
+      for (int i = 0; i < 3; ++i) acc = pti_is_identity(acc) ? pti_from_affi(qi) : pti_madd(acc, qi);
+      r = pti_to_ext(acc);
+    }
   }
   po[t] = r;
 }
 
-constexpr int kTestOpMax = 25;
+constexpr int kTestOpMax = 26;
 MSM_HD bool test_op_is_point(int op) { return (op >= 10 && op <= 13) || op >= 22; }
 
 }  // namespace msm_amd

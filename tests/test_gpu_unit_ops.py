@@ -101,3 +101,28 @@ def test_ec_ops(cfg, msm_pkg):
     flat = cfg.test_op(msm_pkg.OP_EC_MUL, a, kb, cnt)
     got = [decode_be32_affine(flat[24 * i:24 * i + 24]) for i in range(cnt)]
     assert got == [o.scalar_mul(k, p) if p is not None else None for k, (p, _) in zip(ks, cases)]
+
+
+def test_ec29_device_matches_host_twin_and_oracle(cfg, msm_pkg):
+    """The internal-representation point ops (incl. the affine + affine start of a work item, op 26) on the GPU:
+    same answers as the host build of the same code and as the oracle."""
+    rng = random.Random(26)
+    P = [rand_point(rng) for _ in range(12)]
+    cases = [(P[i], P[i + 1]) for i in range(0, 8, 2)] + [(P[8], P[8]), (P[9], o.aff_neg(P[9])),
+                                                          (o.scalar_mul(2, P[0]), o.aff_neg(P[0]))]
+    cnt = len(cases)
+    a = sum((o.encode_point_be32(o.to_jac(p)) for p, _ in cases), [])
+    b = sum((o.encode_point_be32(o.to_jac(q)) for _, q in cases), [])
+    for op in (msm_pkg.OP_EC29_MMADD, msm_pkg.OP_EC29_MADD, msm_pkg.OP_EC29_ADD, msm_pkg.OP_EC29_MADD_CHAIN):
+        dev = cfg.test_op(op, a, b, cnt)
+        assert list(dev) == list(msm_pkg.test_op_host(op, a, b, cnt)), op
+
+    def expect(p, q):
+        np_, nq = o.aff_neg(p), o.aff_neg(q)
+        acc = o.aff_add(np_, nq)
+        for _ in range(3):
+            acc = nq if acc is None else o.aff_add(acc, nq)
+        return acc
+
+    dev = cfg.test_op(msm_pkg.OP_EC29_MMADD, a, b, cnt)
+    assert [decode_be32_affine(dev[24 * i:24 * i + 24]) for i in range(cnt)] == [expect(p, q) for p, q in cases]

@@ -103,3 +103,34 @@ def test_ec29_long_accumulation_keeps_bounds(msm_pkg):
         acc = o.aff_add(acc, q)
         accj = o.decode_point_be32(out)
         assert decode_be32_affine(out) == acc
+
+
+def _mmadd_cases(rng):
+    P = [rand_point(rng) for _ in range(10)]
+    cases = [(P[i], P[i + 1]) for i in range(0, 8, 2)]
+    cases += [(P[8], P[8])]                          # equal points: the exact slow path doubles
+    cases += [(P[9], o.aff_neg(P[9]))]               # opposite points: identity, then the chain restarts from -b
+    cases += [(o.scalar_mul(2, P[0]), o.aff_neg(P[0]))]   # the chain passes through a doubling: (-2P + P) + P ...
+    return cases
+
+
+def _mmadd_expect(p, q):
+    # op 26 negates both operands, adds them affine + affine, then adds -q three more times (restarting from -q
+    # whenever the accumulator is the identity, as the accumulate kernel does)
+    np_, nq = o.aff_neg(p), o.aff_neg(q)
+    acc = o.aff_add(np_, nq)
+    for _ in range(3):
+        acc = nq if acc is None else o.aff_add(acc, nq)
+    return acc
+
+
+def test_ec29_affine_plus_affine_start_of_item(msm_pkg):
+    """pti_mmadd (4M + 2S, the second point of every work item in accumulate_kernel) on lazily negated operands,
+    followed by mixed additions that consume its lazy result."""
+    rng = random.Random(26)
+    cases = _mmadd_cases(rng)
+    a = sum((o.encode_point_be32(o.to_jac(p)) for p, _ in cases), [])
+    b = sum((o.encode_point_be32(o.to_jac(q)) for _, q in cases), [])
+    flat = msm_pkg.test_op_host(msm_pkg.OP_EC29_MMADD, a, b, len(cases))
+    got = [decode_be32_affine(flat[24 * i:24 * i + 24]) for i in range(len(cases))]
+    assert got == [_mmadd_expect(p, q) for p, q in cases]
