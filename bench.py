@@ -137,6 +137,19 @@ def main():
                 "whole_pipeline_GBps": round(L.msm_amd_algorithmic_bytes(n, window, 0) /
                                              (sum(tot_ms) / len(tot_ms) * 1e-3) / 1e9, 2)}
 
+    # ---- secondary roof (SURVEY 8d asks for it): the kernel is bound by quarter-rate 32-bit multiplies, not by HBM.
+    # Instruction counts from csrc/bn254_fq29.hip.h: a 9-limb Montgomery product is 81 + 81 v_mad_u64_u32 + 9
+    # v_mul_lo_u32 = 171 multiplier-pipe instructions, a squaring 135, two products with one reduction 252; a mixed
+    # addition (7 mul + 2 sqr + 1 double product) 1719, the affine+affine start of a work item 1035.  Peak: 1.81 wave
+    # instructions/ns/CU measured for v_mad_u64_u32 (profiles/r01_valu_rates_microbench.txt) x 256 CUs x 64 lanes.
+    items = float(tm.reserved2[0])
+    lane_madds = n * tm.num_windows - 2.0 * items          # first point of an item is free, second is the 1035 one
+    mul_instr = lane_madds * 1719.0 + items * 1035.0
+    valu = {"bound": "valu-int32-multiply", "achieved": round(mul_instr / (acc_avg_ms * 1e-3) / 1e12, 2),
+            "peak": 29.65, "unit": "T lane-instr/s", "frac": round(mul_instr / (acc_avg_ms * 1e-3) / 29.65e12, 4),
+            "work_items": int(items)}
+    roofline["secondary"] = valu
+
     # ---- CPU baseline (rank 0, single-GPU run only): the oracle's restatement of halo2curves msm_best
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

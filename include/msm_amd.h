@@ -75,7 +75,7 @@ typedef struct msm_amd_timings {
   uint32_t num_windows;
   uint32_t reserved;            /* number of instances the averages were taken over */
   float accumulate_kernel_ms;   /* accumulate_kernel alone (events directly around its launch) */
-  float reserved2[3];
+  float reserved2[3];           /* [0] = work items of the last instance's accumulate grid (exact below 2^24) */
 } msm_amd_timings;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

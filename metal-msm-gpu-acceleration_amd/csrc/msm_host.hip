@@ -279,7 +279,8 @@ int slot_prepare(msm_amd_ctx* ctx, InstanceSlot& s, size_t partial_count) {
   if (partial_count > s.h_partial_cap) {
     if (s.h_partial) HIP_TRY(ctx, hipHostFree(s.h_partial));
     s.h_partial = nullptr;
-    HIP_TRY(ctx, hipHostMalloc((void**)&s.h_partial, partial_count * sizeof(Jacobian), hipHostMallocDefault));
+    // one extra record at the end receives the plan counters of the instance (work-item statistics for timings)
+    HIP_TRY(ctx, hipHostMalloc((void**)&s.h_partial, (partial_count + 1) * sizeof(Jacobian), hipHostMallocDefault));
     s.h_partial_cap = partial_count;
   }
   return MSM_AMD_OK;
@@ -469,6 +470,8 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   if ((rc = enqueue_reduce(ctx, w, rs, p, (const PtI*)w.buckets.p))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial, w.partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, rs));
+  HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial + slot.h_partial_cap, w.counters.p, sizeof(PlanCounters),
+                              hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_REDUCE], rs));
   HIP_TRY(ctx, hipEventRecord(w.reduce_done, rs));
   w.reduce_pending = true;
@@ -505,6 +508,9 @@ void accumulate_timings(msm_amd_ctx* ctx, InstanceSlot& s, const Plan& p, float 
   T.window_size = p.c;
   T.num_windows = p.W;
   T.reserved = (uint32_t)n_inst;
+  PlanCounters pc;
+  std::memcpy(&pc, s.h_partial + s.h_partial_cap, sizeof pc);
+  T.reserved2[0] = (float)pc.total_items;   // work items (= lanes with work) of the last instance's accumulate grid
 }
 
 // Batch of MSMs with device-resident inputs, in two halves so that callers can pipeline batches:
