@@ -139,3 +139,33 @@ def test_point_range_split_on_one_gpu(cfg, msm_pkg):
     finally:
         cfg.free(dp)
         cfg.free(ds)
+
+
+def test_log24_ark_projective_dlog_identity(cfg, msm_pkg):
+    """configs[4] (2^24 points, arkworks G1Projective layout, z = one): the dlog identity
+    MSM(k, (a0 + i d) G) == (sum k_i (a0 + i d)) G needs no MSM code on the checking side, so it scales to the
+    full size.  ~1.5 GiB of bases are built on the host from the oracle's dlog generator."""
+    import numpy as np
+    n = 1 << 24
+    rng = random.Random(2024)
+    a0, d = rng.randrange(o.R_ORDER), rng.randrange(o.R_ORDER)
+    dp, ds = cfg.generate_instance(o.SEED_BASE + 240, n, True)        # scalars from the device generator
+    cfg.free(dp)
+    d_proj = None
+    try:
+        sb = cfg.to_host(ds, 32 * n)
+        pb, expect = co.dlog_instance(a0, d, sb, n)                    # affine, 64 B each
+        one = np.frombuffer(o.int_to_le_bytes32(o.MONT_R % o.P), dtype=np.uint8)
+        proj = np.empty((n, 96), dtype=np.uint8)
+        proj[:, :64] = np.frombuffer(pb, dtype=np.uint8).reshape(n, 64)
+        proj[:, 64:] = one
+        del pb
+        d_proj = cfg.alloc(96 * n)
+        cfg.to_device(d_proj, proj.tobytes())
+        del proj
+        out = cfg.msm_batch_device([ds], [d_proj], [n], point_layout=msm_pkg.POINT_ARK_PROJECTIVE)[0]
+        assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(expect)
+    finally:
+        cfg.free(ds)
+        if d_proj is not None:
+            cfg.free(d_proj)
