@@ -26,6 +26,10 @@ def main():
     ap.add_argument("--log-size", type=int, default=20)
     ap.add_argument("--instances", type=int, default=5, help="instances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precomputed-tables", action="store_true",
+                    help="NOT the headline: window tables 2^(c w) P precomputed once per set of bases (SURVEY §8f N4), "
+                         "one bucket set, c = log2(n) - 1")
+    ap.add_argument("--table-window", type=int, default=0, help="window bits of --precomputed-tables (0 = automatic)")
     ap.add_argument("--persistent-bases", action="store_true",
                     help="NOT the headline: bases converted once and kept resident (SURVEY §8f N4); the default "
                          "re-converts them inside every MSM like the reference does (msm.rs:152-153)")
@@ -57,7 +61,14 @@ def main():
         d_sc.append(ds)
     ns = [n] * inst
     point_layout = m.POINT_H2C_AFFINE
-    if args.persistent_bases:
+    tables = []
+    if args.precomputed_tables:
+        tables = [cfg.tables_build_device(dp, n, window_size=args.table_window) for dp in d_pts]
+        for dp in d_pts:
+            cfg.free(dp)
+        d_pts = tables
+        point_layout = m.POINT_TABLES
+    elif args.persistent_bases:
         raw, d_pts = d_pts, [cfg.bases_prepare_device(dp, n) for dp in d_pts]
         for dp in raw:
             cfg.free(dp)
@@ -198,7 +209,9 @@ def main():
                        "instances_per_gpu": inst, "log_size": args.log_size, "window_size": window,
                        "parallelism": f"instance-sharded x{world}, RCCL all_gather of 96-byte results",
                        "pipelining": "step k+1 is submitted before step k's results are collected (submit/wait API)",
-                       "bases": "persistent (converted once, NOT the headline configuration)"
+                       "bases": "precomputed window tables (built once, NOT the headline configuration)"
+                                if args.precomputed_tables else
+                                "persistent (converted once, NOT the headline configuration)"
                                 if args.persistent_bases else "converted inside every MSM, as the reference does"},
             "stage_ms_per_msm": {"sort": round(sum(sort_ms) / len(sort_ms), 4),
                                  "accumulate": round(sum(acc_stage_ms) / len(acc_stage_ms), 4),
@@ -211,7 +224,10 @@ def main():
         }
         print(json.dumps(line), flush=True)
     for j in range(inst):
-        cfg.free(d_pts[j])
+        if tables:
+            cfg.tables_free(d_pts[j])
+        else:
+            cfg.free(d_pts[j])
         cfg.free(d_sc[j])
     cfg.close()
     if dist is not None:

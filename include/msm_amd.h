@@ -56,8 +56,9 @@ enum {
                                        (limbs_conversion.rs:123-130) */
   MSM_AMD_POINT_ARK_AFFINE = 2,     /* ark_bn254::G1Affine {x,y,infinity:bool}: 72 B (limbs_conversion.rs:132-137) */
   MSM_AMD_POINT_JAC_BE32 = 3,       /* reference wire layout: 24 x u32 (x,y,z each MS-limb first), Montgomery */
-  MSM_AMD_POINT_PREPARED = 4        /* device-only: 64-byte records written by msm_amd_bases_upload /
+  MSM_AMD_POINT_PREPARED = 4,       /* device-only: 64-byte records written by msm_amd_bases_upload /
                                        msm_amd_bases_prepare_device (opaque internal form of affine points) */
+  MSM_AMD_POINT_TABLES = 5          /* the "points" pointer is a msm_amd_tables handle (precomputed window tables) */
 };
 
 /* Per-stage device times of the last MSM on this ctx, milliseconds, from hipEvents on the ctx stream
@@ -163,6 +164,24 @@ int msm_amd_msm_prepared(msm_amd_ctx* ctx, int scalar_layout, const void* scalar
  * callers that split ONE instance by point range across several GPUs: every rank runs the MSM of its range,
  * the 96-byte partial results are all-gathered, and every rank adds them. */
 int msm_amd_sum_points(const void* points96, size_t count, void* out96);
+
+/* ---- precomputed window tables (fixed bases) ---------------------------------------------------
+ * Beyond the reference: for a fixed set of bases (an SRS) the library can store 2^(c w) P_i for every window w
+ * (W x n x 64 bytes; 0.9 GB for 2^20 points -- HBM is 288 GB).  All windows then share ONE set of 2^(c-1)
+ * buckets, so the window grows to c = log2(n) - 1 and an MSM needs ~18 % fewer point additions at 2^20 points,
+ * with the same results bit for bit.  Build once (about 0.1 s per 2^20 points), then pass the handle as the points
+ * pointer with MSM_AMD_POINT_TABLES to the *_device entry points (n must equal the table's n), or call
+ * msm_amd_msm_tables with host scalars.  window_size 0 = automatic. */
+typedef struct msm_amd_tables msm_amd_tables;
+int msm_amd_tables_build(msm_amd_ctx* ctx, int point_layout, const void* points, size_t n, uint32_t window_size,
+                         msm_amd_tables** out);
+int msm_amd_tables_build_device(msm_amd_ctx* ctx, int point_layout, const void* d_points, size_t n,
+                                uint32_t window_size, msm_amd_tables** out);
+int msm_amd_tables_info(msm_amd_ctx* ctx, const msm_amd_tables* tables, size_t* n, uint32_t* window_size,
+                        uint32_t* num_windows, size_t* device_bytes);
+int msm_amd_tables_free(msm_amd_ctx* ctx, msm_amd_tables* tables);
+int msm_amd_msm_tables(msm_amd_ctx* ctx, const msm_amd_tables* tables, int scalar_layout, const void* scalars,
+                       void* out96);
 
 /* ---- device memory helpers (so callers without a HIP binding can stage data) ------------------ */
 int msm_amd_device_alloc(msm_amd_ctx* ctx, size_t bytes, void** d_ptr);

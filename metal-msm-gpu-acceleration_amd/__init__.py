@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("MSM_AMD_LIB") or os.path.join(_HERE, "libmsm_amd.so")
 (OK, DEVICE_NOT_FOUND, LIBRARY_ERROR, FUNCTION_ERROR, PIPELINE_ERROR, INPUT_ERROR, FILE_OPEN_ERROR,
  DESERIALIZATION_ERROR, INVALID_DATA) = range(9)
 SCALAR_MONT_LE, SCALAR_CANON_LE, SCALAR_CANON_BE32 = 0, 1, 2
-POINT_H2C_AFFINE, POINT_ARK_PROJECTIVE, POINT_ARK_AFFINE, POINT_JAC_BE32, POINT_PREPARED = 0, 1, 2, 3, 4
+POINT_H2C_AFFINE, POINT_ARK_PROJECTIVE, POINT_ARK_AFFINE, POINT_JAC_BE32, POINT_PREPARED, POINT_TABLES = 0, 1, 2, 3, 4, 5
 POINT_BYTES = {POINT_H2C_AFFINE: 64, POINT_ARK_PROJECTIVE: 96, POINT_ARK_AFFINE: 72, POINT_JAC_BE32: 96}
 (OP_UINT_ADD, OP_UINT_SUB, OP_UINT_PROD, OP_UINT_SHL, OP_UINT_SHR, OP_FP_ADD, OP_FP_SUB, OP_FP_MUL, OP_FP_NEG,
  OP_FP_POW, OP_EC_ADD, OP_EC_MUL, OP_EC_MADD, OP_EC_DBL, OP_FP29_MUL, OP_FP29_SQR, OP_FP29_SUB_K4E30,
@@ -44,7 +44,8 @@ EXPORTS = [
     "msm_amd_instances_save", "msm_amd_instances_open", "msm_amd_instances_count", "msm_amd_instances_size",
     "msm_amd_instances_read", "msm_amd_instances_close", "msm_amd_instances_default_path", "msm_amd_to_wire",
     "msm_amd_from_wire", "msm_amd_sort_pairs_device", "msm_amd_bases_upload", "msm_amd_bases_prepare_device",
-    "msm_amd_msm_prepared", "msm_amd_sum_points",
+    "msm_amd_msm_prepared", "msm_amd_sum_points", "msm_amd_tables_build", "msm_amd_tables_build_device",
+    "msm_amd_tables_info", "msm_amd_tables_free", "msm_amd_msm_tables",
 ]
 
 
@@ -81,6 +82,12 @@ def _lib():
         L.msm_amd_bases_upload.argtypes = [c_void_p, c_int, c_void_p, c_size_t, POINTER(c_void_p)]
         L.msm_amd_bases_prepare_device.argtypes = [c_void_p, c_int, c_void_p, c_size_t, c_void_p]
         L.msm_amd_msm_prepared.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.msm_amd_tables_build.argtypes = [c_void_p, c_int, c_void_p, c_size_t, c_uint32, POINTER(c_void_p)]
+        L.msm_amd_tables_build_device.argtypes = [c_void_p, c_int, c_void_p, c_size_t, c_uint32, POINTER(c_void_p)]
+        L.msm_amd_tables_info.argtypes = [c_void_p, c_void_p, POINTER(c_size_t), POINTER(c_uint32), POINTER(c_uint32),
+                                          POINTER(c_size_t)]
+        L.msm_amd_tables_free.argtypes = [c_void_p, c_void_p]
+        L.msm_amd_msm_tables.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         L.msm_amd_sum_points.argtypes = [c_void_p, c_size_t, c_void_p]
         L.msm_amd_sort_pairs_device.argtypes = [c_void_p, c_void_p, c_size_t, c_uint32, POINTER(c_float)]
         L.msm_amd_instances_save.argtypes = [c_char_p, c_size_t, POINTER(c_size_t), POINTER(c_void_p),
@@ -292,6 +299,33 @@ class MsmConfig:
     def msm_prepared(self, scalars: bytes, d_prepared, n, scalar_layout=SCALAR_MONT_LE) -> bytes:
         out = ctypes.create_string_buffer(96)
         self._check(_lib().msm_amd_msm_prepared(self.h, scalar_layout, scalars, c_void_p(d_prepared), n, out))
+        return out.raw
+
+    # ---- precomputed window tables for fixed bases (beyond the reference) --------
+    def tables_build(self, points: bytes, n: int, point_layout=POINT_H2C_AFFINE, window_size=0) -> int:
+        """Returns a table handle: pass it as the points pointer with POINT_TABLES, free with tables_free."""
+        h = c_void_p()
+        self._check(_lib().msm_amd_tables_build(self.h, point_layout, points, n, window_size, ctypes.byref(h)))
+        return h.value
+
+    def tables_build_device(self, d_points, n, point_layout=POINT_H2C_AFFINE, window_size=0) -> int:
+        h = c_void_p()
+        self._check(_lib().msm_amd_tables_build_device(self.h, point_layout, c_void_p(d_points), n, window_size,
+                                                       ctypes.byref(h)))
+        return h.value
+
+    def tables_info(self, tables):
+        n, nbytes, c, W = c_size_t(), c_size_t(), c_uint32(), c_uint32()
+        self._check(_lib().msm_amd_tables_info(self.h, c_void_p(tables), ctypes.byref(n), ctypes.byref(c),
+                                               ctypes.byref(W), ctypes.byref(nbytes)))
+        return {"n": n.value, "window_size": c.value, "num_windows": W.value, "device_bytes": nbytes.value}
+
+    def tables_free(self, tables):
+        self._check(_lib().msm_amd_tables_free(self.h, c_void_p(tables)))
+
+    def msm_tables(self, scalars: bytes, tables, scalar_layout=SCALAR_MONT_LE) -> bytes:
+        out = ctypes.create_string_buffer(96)
+        self._check(_lib().msm_amd_msm_tables(self.h, c_void_p(tables), scalar_layout, scalars, out))
         return out.raw
 
     def sort_pairs_device(self, d_pairs, n_pairs, key_bits=32) -> float:

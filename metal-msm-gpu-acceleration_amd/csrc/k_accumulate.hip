@@ -24,7 +24,7 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
                   const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
                   const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
                   uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
-  if (LOW_OCC) asm volatile("v_mov_b32 v190, 0" ::: "v190");
+  if (LOW_OCC) asm volatile("v_mov_b32 v175, 0" ::: "v175");   // 176 allocated: 2 waves/SIMD, 160 VGPRs left free
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= counters->total_items) return;
   const uint2 it = order[slot];
@@ -104,20 +104,22 @@ combine_small_kernel(const uint32_t* __restrict__ multi_list, PlanCounters* __re
                      const uint32_t* __restrict__ bucket_size, const uint32_t* __restrict__ item_start,
                      const uint32_t* __restrict__ win_base, uint32_t lb, uint32_t CH,
                      const PtI* __restrict__ partials, PtI* __restrict__ buckets, uint32_t* __restrict__ big_list) {
-  const uint32_t count = counters->multi_count;
-  for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < count; m += gridDim.x * blockDim.x) {
-    const uint32_t b = multi_list[m];
-    const uint32_t nitems = (bucket_size[b] + CH - 1) / CH;
-    if (nitems <= kSerialItems) {
-      const PtI* src = partials + (size_t)win_base[b >> lb] + item_start[b];
-      PtI acc = load_pti(&src[0]);
-#pragma unroll 1
-      for (uint32_t i = 1; i < nitems; ++i) acc = pti_add(acc, load_pti(&src[i]));
-      store_pti(&buckets[b], acc);
-    } else {
-      big_list[atomicAdd(&counters->pad[0], 1u)] = b;   // pad[0] = number of deferred buckets
-    }
+  // the grid covers every possible split bucket (one lane each, launch_combine): no grid-stride loop, which keeps
+  // the kernel at <= 160 VGPRs so that its waves fit beside two accumulate waves of the next instance
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= counters->multi_count) return;
+  const uint32_t b = multi_list[m];
+  const uint32_t nitems = (bucket_size[b] + CH - 1) / CH;
+  if (nitems > kSerialItems) {
+    big_list[atomicAdd(&counters->pad[0], 1u)] = b;   // pad[0] = number of deferred buckets
+    return;
   }
+  const PtI* src = partials + (size_t)win_base[b >> lb] + item_start[b];
+  const PtI* const end = src + nitems;
+  PtI acc = load_pti(src);
+#pragma unroll 1
+  for (++src; src != end; ++src) acc = pti_add(acc, load_pti(src));
+  store_pti(&buckets[multi_list[m]], acc);   // b is re-read: one live register less across the loop
 }
 
 __global__ void __launch_bounds__(64)

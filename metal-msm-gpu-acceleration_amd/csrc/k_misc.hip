@@ -43,6 +43,32 @@ convert_bases_kernel(const Affine* __restrict__ in, uint32_t n, AffPacked* __res
   store_affi(&out[t], affi_from_ext(load_affine(&in[t])));
 }
 
+// Precomputed window tables: tables[w * n + i] = 2^(c w) P_i for w = 0 .. W-1, in the packed internal
+// form, so that window w of scalar i adds into the SAME bucket set as window 0: one set of 2^(c-1) buckets serves
+// all windows and c can grow to 18..20 (about 18 % fewer additions at 2^20 points).  One thread per point walks the
+// windows: c doublings on the external Jacobian form, one inversion per table entry.  A set-up cost (~0.1 s per
+// 2^20 points), paid once per SRS.
+__global__ void __launch_bounds__(64)
+build_tables_kernel(const Affine* __restrict__ in, uint32_t n, uint32_t c, uint32_t W, AffPacked* __restrict__ tables) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  Affine a = load_affine(&in[t]);
+  store_affi(&tables[t], affi_from_ext(a));
+  Jacobian p = affine_is_identity(a) ? jac_identity() : jac_from_affine(a);
+#pragma unroll 1
+  for (uint32_t w = 1; w < W; ++w) {
+#pragma unroll 1
+    for (uint32_t i = 0; i < c; ++i) p = jac_double(p);
+    a = jac_to_affine(p);                    // identity stays (0, 0)
+    p = affine_is_identity(a) ? jac_identity() : jac_from_affine(a);   // z back to one: cheaper doublings
+    store_affi(&tables[(size_t)w * n + t], affi_from_ext(a));
+  }
+}
+
+void launch_build_tables(hipStream_t st, const Affine* in, uint32_t n, uint32_t c, uint32_t W, AffPacked* tables) {
+  hipLaunchKernelGGL(build_tables_kernel, dim3((n + 63) / 64), dim3(64), 0, st, in, n, c, W, tables);
+}
+
 void launch_convert_bases(hipStream_t st, const Affine* in, uint32_t n, AffPacked* out) {
   hipLaunchKernelGGL(convert_bases_kernel, dim3((n + 127) / 128), dim3(128), 0, st, in, n, out);
 }

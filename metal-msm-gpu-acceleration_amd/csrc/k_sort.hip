@@ -17,9 +17,13 @@ constexpr int kSortThreads = 1024;       // hist / plan / scatter workgroup size
 // -P, which costs one field negation of y.  Output per (window, point): u16 = sign << 15 | magnitude
 // (magnitude 0 = no contribution).  scalars_mont: 1 = host Montgomery form (bn256::Fr / ark Fr memory; the
 // reference de-Montgomerys on the CPU, limbs_conversion.rs:282-288), 0 = canonical integer.
+// D = uint16_t (c <= 15: the per-call pipeline) or uint32_t (c <= 24: precomputed window tables, where the
+// [W][n] digit matrix is consumed as ONE window of W * n entries, see make_table_plan in msm_host.hip).
+template <typename D>
 __global__ void __launch_bounds__(256)
 digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W, int scalars_mont,
-              uint16_t* __restrict__ digits) {
+              D* __restrict__ digits) {
+  constexpr uint32_t kSignShift = 8 * sizeof(D) - 1;
   __builtin_amdgcn_s_setprio(kFrontPriority);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -37,7 +41,7 @@ digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t
       neg = 1;
       carry = 1;
     }
-    digits[(size_t)w * n + t] = (uint16_t)(v | (neg << 15));
+    digits[(size_t)w * n + t] = (D)(v | (neg << kSignShift));
   }
 }
 
@@ -59,9 +63,11 @@ digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t
 // The reference sorts 8-byte (bucket, point) pairs of ALL windows on the CPU (sort_buckets.rs:15-34).
 constexpr uint32_t kFineCap = 28672;     // LDS staging entries of pass 2 (112 KB)
 
+template <typename D>
 __global__ void __launch_bounds__(kSortThreads)
-coarse_hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t fb, uint32_t nhi, uint32_t chunk,
+coarse_hist_kernel(const D* __restrict__ digits, uint32_t n, uint32_t fb, uint32_t nhi, uint32_t chunk,
                    uint32_t* __restrict__ coarse_cnt /* [W][Q][nhi] */) {
+  constexpr uint32_t kMagMask = (1u << (8 * sizeof(D) - 1)) - 1u;
   __builtin_amdgcn_s_setprio(kFrontPriority);
   extern __shared__ uint32_t lds_u32[];
   const uint32_t q = blockIdx.x, Q = gridDim.x, w = blockIdx.y;
@@ -69,9 +75,9 @@ coarse_hist_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t fb,
   __syncthreads();
   const uint32_t lo = q * chunk;
   const uint32_t hi = min(n, lo + chunk);
-  const uint16_t* dw = digits + (size_t)w * n;
+  const D* dw = digits + (size_t)w * n;
   for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
-    const uint32_t m = dw[t] & 0x7FFFu;
+    const uint32_t m = dw[t] & kMagMask;
     if (m) atomicAdd(&lds_u32[(m - 1) >> fb], 1u);
   }
   __syncthreads();
@@ -89,13 +95,16 @@ coarse_prefix_kernel(uint32_t* __restrict__ coarse_cnt, uint32_t Q, uint32_t nhi
   const uint32_t w = blockIdx.x, hi = threadIdx.x;
   uint32_t* cw = coarse_cnt + (size_t)w * Q * nhi;
   uint32_t tot = 0;
-  if (hi < nhi)
-    for (uint32_t q = 0; q < Q; ++q) tot += cw[(size_t)q * nhi + hi];
+  if (hi < nhi) {
+#pragma unroll 8
+    for (uint32_t q = 0; q < Q; ++q) tot += cw[(size_t)q * nhi + hi];   // independent loads: keep 8 in flight
+  }
   uint32_t total;
   uint32_t start = block_exclusive_scan(tot, scratch, &total);
   if (hi < nhi) {
     region_start[(size_t)w * (nhi + 1) + hi] = start;
     uint32_t run = start;
+#pragma unroll 8
     for (uint32_t q = 0; q < Q; ++q) {
       const uint32_t c = cw[(size_t)q * nhi + hi];
       cw[(size_t)q * nhi + hi] = run;
@@ -108,8 +117,9 @@ coarse_prefix_kernel(uint32_t* __restrict__ coarse_cnt, uint32_t Q, uint32_t nhi
 // grid = (Q, W), block = 1024, dynamic LDS = nhi * 4 bytes.  The workgroup owns ONE contiguous run per region
 // (coarse_base[w][q][hi] ..): lanes take positions with a returning LDS atomic on the region cursor, so the
 // 2^hb open output lines of a workgroup are written by its own 16 waves only and complete inside one L2.
+template <typename D>
 __global__ void __launch_bounds__(kSortThreads)
-coarse_scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t hb, uint32_t fb, uint32_t chunk,
+coarse_scatter_kernel(const D* __restrict__ digits, uint32_t n, uint32_t hb, uint32_t fb, uint32_t chunk,
                       const uint32_t* __restrict__ coarse_base /* [W][Q][nhi] */, uint32_t* __restrict__ tmp_idx,
                       uint16_t* __restrict__ tmp_fine) {
   __builtin_amdgcn_s_setprio(kFrontPriority);
@@ -121,17 +131,19 @@ coarse_scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t 
   __syncthreads();
   const uint32_t lo = q * chunk;
   const uint32_t hi_end = min(n, lo + chunk);
-  const uint16_t* dw = digits + (size_t)w * n;
+  constexpr uint32_t kSignShift = 8 * sizeof(D) - 1;
+  constexpr uint32_t kMagMask = (1u << kSignShift) - 1u;
+  const D* dw = digits + (size_t)w * n;
   uint32_t* ti = tmp_idx + (size_t)w * n;
   uint16_t* tf = tmp_fine + (size_t)w * n;
   const uint32_t fmask = (1u << fb) - 1u;
   for (uint32_t t = lo + threadIdx.x; t < hi_end; t += blockDim.x) {
     const uint32_t v = dw[t];
-    const uint32_t m = v & 0x7FFFu;
+    const uint32_t m = v & kMagMask;
     if (m) {
       const uint32_t slot = m - 1;
       const uint32_t pos = atomicAdd(&lds_u32[slot >> fb], 1u);
-      ti[pos] = t | ((v >> 15) << 31);   // bit 31: the digit is negative, add -P
+      ti[pos] = t | ((v >> kSignShift) << 31);   // bit 31: the digit is negative, add -P
       tf[pos] = (uint16_t)(slot & fmask);
     }
   }
@@ -223,31 +235,69 @@ __device__ __forceinline__ uint32_t window_scan_lds(uint32_t* tot, uint32_t* scr
   return total;
 }
 
+// Windows of more than kPlanTile slots (precomputed-table mode: one window of 2^15 .. 2^20 slots) are scanned by one
+// workgroup per tile: plan_tile_sums_kernel first writes every tile's totals, plan_kernel then adds the totals of
+// the tiles before its own.  The per-call pipeline (<= 2^14 slots per window) is a single tile and skips the
+// first kernel.
+constexpr uint32_t kPlanTile = 16384;
+
+// grid = (tiles, W): tile_sums[w][tile] = (points, work items) of the tile
 __global__ void __launch_bounds__(kSortThreads)
-plan_kernel(const uint32_t* __restrict__ bucket_size, uint32_t lb, uint32_t CH,
+plan_tile_sums_kernel(const uint32_t* __restrict__ bucket_size, uint32_t lb, uint32_t CH, uint2* __restrict__ tile_sums) {
+  __builtin_amdgcn_s_setprio(kFrontPriority);
+  __shared__ uint32_t scratch[17];
+  const uint32_t nb = 1u << lb, tile = min(nb, kPlanTile);
+  const uint32_t* bsz = bucket_size + (size_t)blockIdx.y * nb + (size_t)blockIdx.x * tile;
+  uint32_t pts = 0, items = 0;
+#pragma unroll 4
+  for (uint32_t d = threadIdx.x; d < tile; d += blockDim.x) {
+    const uint32_t v = bsz[d];
+    pts += v;
+    items += (v + CH - 1) / CH;
+  }
+  uint32_t tp, ti;
+  (void)block_exclusive_scan(pts, scratch, &tp);
+  (void)block_exclusive_scan(items, scratch, &ti);
+  if (threadIdx.x == 0) tile_sums[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = make_uint2(tp, ti);
+}
+
+// grid = (tiles, W), block = front_threads, dynamic LDS = lds_plan_bytes(lb)
+__global__ void __launch_bounds__(kSortThreads)
+plan_kernel(const uint32_t* __restrict__ bucket_size, uint32_t lb, uint32_t CH, const uint2* __restrict__ tile_sums,
             uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ item_start,
             uint32_t* __restrict__ win_items) {
   __builtin_amdgcn_s_setprio(kFrontPriority);
   extern __shared__ uint32_t lds_u32[];
   const uint32_t nb = 1u << lb;
-  const uint32_t w = blockIdx.x;
-  uint32_t* tot = lds_u32;                               // skewed: index i lives at i + (i >> 5)
-  uint32_t* scratch = lds_u32 + nb + (nb >> 5) + 1;      // 17 words
-  const uint32_t* bsz = bucket_size + (size_t)w * nb;
+  const uint32_t tile = min(nb, kPlanTile);
+  const uint32_t w = blockIdx.y, tiles = gridDim.x;
+  uint32_t* tot = lds_u32;                                   // skewed: index i lives at i + (i >> 5)
+  uint32_t* scratch = lds_u32 + tile + (tile >> 5) + 1;      // 17 words
+  uint32_t carry_start = 0, carry_items = 0;
+  if (tiles > 1) {   // a few dozen tiles at most: every thread adds them up itself
 #pragma unroll 1
-  for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) tot[d + (d >> 5)] = bsz[d];
+    for (uint32_t t = 0; t < blockIdx.x; ++t) {
+      const uint2 v = tile_sums[(size_t)w * tiles + t];
+      carry_start += v.x;
+      carry_items += v.y;
+    }
+  }
+  const size_t base = (size_t)w * nb + (size_t)blockIdx.x * tile;
+  const uint32_t* bsz = bucket_size + base;
+#pragma unroll 1
+  for (uint32_t d = threadIdx.x; d < tile; d += blockDim.x) tot[d + (d >> 5)] = bsz[d];
   __syncthreads();
-  window_scan_lds(tot, scratch, nb);
+  window_scan_lds(tot, scratch, tile);
 #pragma unroll 1
-  for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) bucket_start[(size_t)w * nb + d] = tot[d + (d >> 5)];
+  for (uint32_t d = threadIdx.x; d < tile; d += blockDim.x) bucket_start[base + d] = carry_start + tot[d + (d >> 5)];
   __syncthreads();
 #pragma unroll 1
-  for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) tot[d + (d >> 5)] = (bsz[d] + CH - 1) / CH;
+  for (uint32_t d = threadIdx.x; d < tile; d += blockDim.x) tot[d + (d >> 5)] = (bsz[d] + CH - 1) / CH;
   __syncthreads();
-  const uint32_t total_items = window_scan_lds(tot, scratch, nb);
+  const uint32_t tile_items = window_scan_lds(tot, scratch, tile);
 #pragma unroll 1
-  for (uint32_t d = threadIdx.x; d < nb; d += blockDim.x) item_start[(size_t)w * nb + d] = tot[d + (d >> 5)];
-  if (threadIdx.x == 0) win_items[w] = total_items;
+  for (uint32_t d = threadIdx.x; d < tile; d += blockDim.x) item_start[base + d] = carry_items + tot[d + (d >> 5)];
+  if (threadIdx.x == 0 && blockIdx.x == tiles - 1) win_items[w] = carry_items + tile_items;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -390,13 +440,18 @@ be32_to_le_kernel(const uint32_t* __restrict__ in, size_t words, uint32_t* __res
 
 
 // ------------------------------------------------------------------------------------------------
-static size_t lds_plan_bytes(uint32_t lb) { return ((size_t)(1u << lb) + ((1u << lb) >> 5) + 33) * 4; }
+static size_t lds_plan_bytes(uint32_t lb) {
+  const size_t tile = std::min<size_t>((size_t)1 << lb, kPlanTile);
+  return (tile + (tile >> 5) + 33) * 4;
+}
 
 int sort_set_attributes(const char** failed) {
   const int max_lds = 160 * 1024;
-  struct { const void* fn; const char* name; } ks[] = {{(const void*)plan_kernel, "plan_kernel"},
-                                                        {(const void*)coarse_scatter_kernel, "coarse_scatter_kernel"},
-                                                        {(const void*)fine_sort_kernel, "fine_sort_kernel"}};
+  struct { const void* fn; const char* name; } ks[] = {
+      {(const void*)plan_kernel, "plan_kernel"},
+      {(const void*)coarse_scatter_kernel<uint16_t>, "coarse_scatter_kernel<u16>"},
+      {(const void*)coarse_scatter_kernel<uint32_t>, "coarse_scatter_kernel<u32>"},
+      {(const void*)fine_sort_kernel, "fine_sort_kernel"}};
   for (auto& k : ks) {
     if (hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess) {
       (void)hipGetLastError();
@@ -407,24 +462,43 @@ int sort_set_attributes(const char** failed) {
   return 0;
 }
 
-void launch_digits(hipStream_t st, const Plan& p, const u256* scalars, int scalars_mont, uint16_t* digits) {
-  hipLaunchKernelGGL(digits_kernel, dim3((p.n + 255) / 256), dim3(256), 0, st, scalars, p.n, p.c, p.W, scalars_mont,
-                     digits);
+void launch_digits(hipStream_t st, const Plan& p, const u256* scalars, int scalars_mont, void* digits) {
+  const dim3 grid((p.n_scalars + 255) / 256), block(256);
+  if (p.wide_digits)
+    hipLaunchKernelGGL(digits_kernel<uint32_t>, grid, block, 0, st, scalars, p.n_scalars, p.c, p.W_digits, scalars_mont,
+                       (uint32_t*)digits);
+  else
+    hipLaunchKernelGGL(digits_kernel<uint16_t>, grid, block, 0, st, scalars, p.n_scalars, p.c, p.W_digits, scalars_mont,
+                       (uint16_t*)digits);
 }
 
 void launch_sort(hipStream_t st, const Plan& p, const SortBuffers& b) {
   const uint32_t nhi = 1u << p.hb, nfine = 1u << p.fb;
-  hipLaunchKernelGGL(coarse_hist_kernel, dim3(p.Q, p.W), dim3(p.front_threads), nhi * 4, st,
-                     (const uint16_t*)b.digits, p.n, p.fb, nhi, p.chunk, b.coarse_cnt);
+  if (p.wide_digits)
+    hipLaunchKernelGGL(coarse_hist_kernel<uint32_t>, dim3(p.Q, p.W), dim3(p.front_threads), nhi * 4, st,
+                       (const uint32_t*)b.digits, p.n, p.fb, nhi, p.chunk, b.coarse_cnt);
+  else
+    hipLaunchKernelGGL(coarse_hist_kernel<uint16_t>, dim3(p.Q, p.W), dim3(p.front_threads), nhi * 4, st,
+                       (const uint16_t*)b.digits, p.n, p.fb, nhi, p.chunk, b.coarse_cnt);
   hipLaunchKernelGGL(coarse_prefix_kernel, dim3(p.W), dim3(1024), 0, st, b.coarse_cnt, p.Q, nhi, b.region_start);
-  hipLaunchKernelGGL(coarse_scatter_kernel, dim3(p.Q, p.W), dim3(p.front_threads), nhi * 4, st,
-                     (const uint16_t*)b.digits, p.n, p.hb, p.fb, p.chunk, (const uint32_t*)b.coarse_cnt, b.tmp_idx,
-                     b.tmp_fine);
+  if (p.wide_digits)
+    hipLaunchKernelGGL(coarse_scatter_kernel<uint32_t>, dim3(p.Q, p.W), dim3(p.front_threads), nhi * 4, st,
+                       (const uint32_t*)b.digits, p.n, p.hb, p.fb, p.chunk, (const uint32_t*)b.coarse_cnt, b.tmp_idx,
+                       b.tmp_fine);
+  else
+    hipLaunchKernelGGL(coarse_scatter_kernel<uint16_t>, dim3(p.Q, p.W), dim3(p.front_threads), nhi * 4, st,
+                       (const uint16_t*)b.digits, p.n, p.hb, p.fb, p.chunk, (const uint32_t*)b.coarse_cnt, b.tmp_idx,
+                       b.tmp_fine);
   hipLaunchKernelGGL(fine_sort_kernel, dim3(nhi, p.W), dim3(std::max(p.front_threads, nfine)), (kFineCap + nfine + 32) * 4, st,
                      (const uint32_t*)b.tmp_idx, (const uint16_t*)b.tmp_fine, p.n, p.lb, p.fb,
                      (const uint32_t*)b.region_start, b.sorted, b.bucket_size);
-  hipLaunchKernelGGL(plan_kernel, dim3(p.W), dim3(p.front_threads), lds_plan_bytes(p.lb), st,
-                     (const uint32_t*)b.bucket_size, p.lb, p.CH, b.bucket_start, b.item_start, b.win_items);
+  const unsigned tiles = (unsigned)((p.nb + kPlanTile - 1) / kPlanTile);
+  if (tiles > 1)
+    hipLaunchKernelGGL(plan_tile_sums_kernel, dim3(tiles, p.W), dim3(p.front_threads), 0, st,
+                       (const uint32_t*)b.bucket_size, p.lb, p.CH, b.tile_sums);
+  hipLaunchKernelGGL(plan_kernel, dim3(tiles, p.W), dim3(p.front_threads), lds_plan_bytes(p.lb), st,
+                     (const uint32_t*)b.bucket_size, p.lb, p.CH, (const uint2*)b.tile_sums, b.bucket_start,
+                     b.item_start, b.win_items);
   const unsigned size_threads = p.front_threads;
   const unsigned gb = (unsigned)((p.total_buckets + size_threads - 1) / size_threads);
   hipLaunchKernelGGL(size_hist_kernel, dim3(gb), dim3(size_threads), (p.CH + 1) * 4, st,

@@ -14,14 +14,18 @@ constexpr int kSeg = 1 << kSegLog;
 
 // Geometry of one MSM (see make_plan in msm_host.hip).
 struct Plan {
-  uint32_t n, c, W;           // points, window bits, windows (signed digits: W = floor(254/c) + 1)
+  uint32_t n, c, W;           // sorted entries per window, window bits, windows that own buckets
+                              // (per-call pipeline: n points, W = floor(254/c) + 1 signed-digit windows;
+                              //  precomputed tables: n = W_digits * n_scalars entries in ONE window)
+  uint32_t n_scalars, W_digits;   // what digits_kernel sees: scalars and digit windows per scalar
+  bool wide_digits;           // digits are u32 (c up to 24) instead of u16 (c <= 15)
   uint32_t lb, nb;            // bucket slots per window nb = 2^lb = max(2^(c-1), 8); slot i holds |digit| = i + 1
   uint32_t Q, chunk;          // sort: chunks per window, points per chunk
   uint32_t hb, fb;            // sort: coarse / fine bits of the slot (hb + fb = lb)
   uint32_t front_threads;     // workgroup size of the sort / planning kernels (256..1024)
   uint32_t CH;                // accumulate: max points per work item (bucket chunk)
   uint32_t nseg, K;           // reduce: segments per window, bits of segment index (lb - 3)
-  uint32_t tree_threads;
+  uint32_t tree_threads, tree_parts;   // reduce_tree: threads per workgroup, slices per (sum, window)
   size_t total_buckets, total_segs, partial_count, max_items;
 };
 
@@ -33,7 +37,7 @@ struct PlanCounters {
 };
 
 struct SortBuffers {
-  uint16_t* digits;           // [W][n]
+  void* digits;               // [W_digits][n_scalars] u16 or u32 (Plan::wide_digits) = [W][n] entries
   uint32_t* coarse_cnt;       // [W][Q][2^hb]  per-chunk region counts, then write positions
   uint32_t* region_start;     // [W][2^hb + 1]
   uint32_t* tmp_idx;          // [W][n]        pass-1 output: index | sign << 31, grouped by coarse region
@@ -42,6 +46,7 @@ struct SortBuffers {
   uint32_t* bucket_start;     // [W][nb]   offset inside the window's slice of `sorted`
   uint32_t* item_start;       // [W][nb]   first item id of the bucket inside its window
   uint32_t* win_items;        // [W]       items per window, then exclusive prefix (window base)
+  uint2* tile_sums;           // [W][tiles] (points, items) per planning tile (windows of more than 16384 slots)
   uint32_t* size_bins;        // [CH + 1][ceil(total_buckets / front_threads)] item-size counts, then positions
   uint32_t* sorted;           // [W][n]
   uint2* order;               // [max_items] (bucket, chunk) by descending size
@@ -51,7 +56,8 @@ struct SortBuffers {
 
 // k_sort.hip
 int sort_set_attributes(const char** failed);
-void launch_digits(hipStream_t st, const Plan& p, const u256* scalars, int scalars_mont, uint16_t* digits);
+void launch_build_tables(hipStream_t st, const Affine* in, uint32_t n, uint32_t c, uint32_t W, AffPacked* tables);
+void launch_digits(hipStream_t st, const Plan& p, const u256* scalars, int scalars_mont, void* digits);
 void launch_sort(hipStream_t st, const Plan& p, const SortBuffers& b);
 void launch_be32_to_le(hipStream_t st, const uint32_t* in, size_t words, uint32_t* out);
 void launch_ark_affine_to_affine(hipStream_t st, const uint8_t* in, uint32_t n, Affine* out);

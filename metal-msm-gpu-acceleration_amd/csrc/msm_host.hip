@@ -61,7 +61,7 @@ struct Workspace {
   bool acc_pending = false, reduce_pending = false;
 };
 
-constexpr int kWorkspaces = 3;
+constexpr int kWorkspaces = 4;
 constexpr int kMaxBatches = 4;   // batches that may be in flight between submit and wait
 
 struct Batch {
@@ -72,10 +72,23 @@ struct Batch {
   bool active = false;
 };
 
+// Precomputed window tables of one set of bases (msm_amd_tables_*): tables[w * n + i] = 2^(c w) P_i, packed form.
+// Handles are validated by membership in msm_amd_ctx::live_tables, never by dereferencing the caller's pointer.
+struct msm_amd_tables {
+  size_t n = 0;
+  uint32_t c = 0, W = 0;
+  void* d_tables = nullptr;   // W * n AffPacked
+};
+
 struct msm_amd_ctx {
   int device = 0;
   hipStream_t stream = nullptr;          // main stream: conversion, digits, sort, accumulate; stage entry points
   hipStream_t reduce_stream = nullptr;   // side stream: window reduction + copy of the partial points
+  hipStream_t reduce_stream2 = nullptr;  // consecutive instances alternate between the two reduce streams: the tail
+                                         // of an instance is a chain of four latency-bound kernels that is as long as
+                                         // one accumulate, so two of them must be able to overlap
+  bool alt_reduce = true;                // MSM_AMD_ALT_REDUCE=0: one reduce stream
+  uint32_t seq = 0;
   hipStream_t front_stream = nullptr;    // side stream: conversion, digits, sort, work-item planning
   bool overlap_reduce = true;            // MSM_AMD_OVERLAP_REDUCE=0 puts the reduction on the main stream
   bool overlap_front = true;             // MSM_AMD_OVERLAP_FRONT=0 puts the front end on the main stream
@@ -83,6 +96,7 @@ struct msm_amd_ctx {
   std::mutex mu;
   std::string last_error;
   uint32_t forced_window = 0;
+  std::vector<msm_amd_tables*> live_tables;
   int next_ws = 0;
   DeviceBuf scratch_a, scratch_b, scratch_c, scratch_b2, scratch_c2;
   Batch batches[kMaxBatches];
@@ -135,11 +149,18 @@ uint32_t auto_window(size_t n) {
   return std::min(kMaxWindow, std::max(4u, c));
 }
 
-Plan make_plan(size_t n, uint32_t c) {
+// `windows` = 0: the per-call pipeline (every signed-digit window owns a bucket set).  `windows` = W_digits > 0: the
+// precomputed-table pipeline, where the [W_digits][n_scalars] digit matrix is sorted as ONE window of
+// W_digits * n_scalars entries whose "point index" addresses the table entry 2^(c w) P_i directly.
+Plan make_plan(size_t n_scalars, uint32_t c, uint32_t windows = 0) {
   Plan p{};
+  const size_t n = windows ? n_scalars * windows : n_scalars;
   p.n = (uint32_t)n;
   p.c = c;
-  p.W = kModulusBits / c + 1;         // signed digits: the top window absorbs the last carry (= ceil(255 / c))
+  p.W_digits = kModulusBits / c + 1;  // signed digits: the top window absorbs the last carry (= ceil(255 / c))
+  p.W = windows ? 1u : p.W_digits;
+  p.n_scalars = (uint32_t)n_scalars;
+  p.wide_digits = c > 15;
   p.lb = std::max(c - 1, (uint32_t)kSegLog);
   p.nb = 1u << p.lb;                  // slot i <-> digit magnitude i + 1 (c = 3 is padded to 8 slots)
   // sort / planning workgroup size: big workgroups are the fastest alone, but they can hardly be placed while
@@ -158,8 +179,10 @@ Plan make_plan(size_t n, uint32_t c) {
   // coarse regions of ~16 k points so that pass 2 sorts a region inside LDS; at least 2 fine bits.  At most 128
   // regions: beyond that pass 1 keeps too many partially written lines open (2^24 points: 10.2 ms with 1024
   // regions, 6.0 ms with 128, whose 131 k-point regions pass 2 scatters directly inside an L2-sized range).
+  // (the single long window of the table pipeline needs regions that fit LDS more than it needs few regions)
   uint32_t hb = 0;
-  while (hb + 2 < p.lb && hb < 7 && (n >> hb) > 16384) ++hb;
+  const uint32_t hb_cap = windows ? 10u : 7u;
+  while (hb + 2 < p.lb && hb < hb_cap && (n >> hb) > 16384) ++hb;
   if (const char* e = std::getenv("MSM_AMD_HB")) {   // experiments: coarse bits of the two-pass sort
     const int v = std::atoi(e);
     if (v >= 0 && (uint32_t)v + 2 <= p.lb) hb = (uint32_t)v;
@@ -185,11 +208,13 @@ Plan make_plan(size_t n, uint32_t c) {
   p.K = p.lb - kSegLog;
   p.total_buckets = (size_t)p.W * p.nb;
   p.total_segs = (size_t)p.W * p.nseg;
-  p.partial_count = (size_t)p.W * (p.K + 2);
   p.max_items = p.total_buckets + ((size_t)p.W * n) / ch + 1;
   uint32_t t = 64;
   while (t < 512 && t < std::max(1u, p.nseg / 2)) t <<= 1;
   p.tree_threads = t;
+  p.tree_parts = 1;   // at most 4 segments per thread and sum (nseg is a power of two, so parts divides it)
+  while (p.tree_parts < 64 && (p.nseg / 2) / p.tree_parts > 4 * t) p.tree_parts <<= 1;
+  p.partial_count = (size_t)p.W * (p.K + 2) * p.tree_parts;
   return p;
 }
 
@@ -204,10 +229,11 @@ Plan make_reduce_plan(uint32_t lb, uint32_t W) {
   p.K = lb - kSegLog;
   p.total_buckets = (size_t)p.W * p.nb;
   p.total_segs = (size_t)p.W * p.nseg;
-  p.partial_count = (size_t)p.W * (p.K + 2);
   uint32_t t = 64;
   while (t < 512 && t < std::max(1u, p.nseg / 2)) t <<= 1;
   p.tree_threads = t;
+  p.tree_parts = 1;
+  p.partial_count = (size_t)p.W * (p.K + 2);
   return p;
 }
 
@@ -250,11 +276,14 @@ Jacobian normalise(const Jacobian& p) {
 Jacobian host_combine(const Jacobian* partial, const Plan& p) {
   const uint32_t top = p.c * p.W;   // exclusive upper bound of bit positions
   std::vector<std::vector<const Jacobian*>> at(top + 1);
+  const uint32_t parts = std::max(1u, p.tree_parts);
   for (uint32_t w = 0; w < p.W; ++w) {
-    const Jacobian* pw = partial + (size_t)w * (p.K + 2);
-    at[p.c * w].push_back(&pw[p.K]);
-    at[p.c * w].push_back(&pw[p.K + 1]);
-    for (uint32_t k = 0; k < p.K; ++k) at[p.c * w + kSegLog + k].push_back(&pw[k]);
+    const Jacobian* pw = partial + (size_t)w * (p.K + 2) * parts;   // [K + 2][parts]
+    for (uint32_t part = 0; part < parts; ++part) {
+      at[p.c * w].push_back(&pw[(size_t)p.K * parts + part]);
+      at[p.c * w].push_back(&pw[(size_t)(p.K + 1) * parts + part]);
+      for (uint32_t k = 0; k < p.K; ++k) at[p.c * w + kSegLog + k].push_back(&pw[(size_t)k * parts + part]);
+    }
   }
   Jacobian acc = jac_identity();
   for (int pos = (int)top; pos >= 0; --pos) {
@@ -354,6 +383,7 @@ size_t point_bytes(int layout) {
   switch (layout) {
     case MSM_AMD_POINT_H2C_AFFINE: return 64;
     case MSM_AMD_POINT_PREPARED: return sizeof(AffPacked);
+    case MSM_AMD_POINT_TABLES: return sizeof(AffPacked);
     case MSM_AMD_POINT_ARK_PROJECTIVE: return 96;
     case MSM_AMD_POINT_ARK_AFFINE: return 72;
     case MSM_AMD_POINT_JAC_BE32: return 96;
@@ -372,16 +402,29 @@ int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, hipStream_t st, const Plan& p
   return MSM_AMD_OK;
 }
 
+const msm_amd_tables* find_tables(const msm_amd_ctx* ctx, const void* handle) {
+  for (const msm_amd_tables* t : ctx->live_tables)
+    if ((const void*)t == handle) return t;
+  return nullptr;
+}
+
 // Enqueue one whole MSM on the ctx stream; results land in slot.h_partial after slot.ev[EV_REDUCE].
 int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_layout, int point_layout, const void* d_scalars,
                 const void* d_points, size_t n, Plan* plan_out) {
   hipStream_t st = ctx->stream;
-  const uint32_t c = ctx->forced_window ? ctx->forced_window : auto_window(n);
-  const Plan p = make_plan(n, c);
+  const msm_amd_tables* tb = nullptr;
+  if (point_layout == MSM_AMD_POINT_TABLES) {   // d_points is the handle of msm_amd_tables_build*
+    tb = find_tables(ctx, d_points);
+    if (!tb) return fail(ctx, MSM_AMD_INPUT_ERROR, "not a table handle of this ctx");
+    if (n != tb->n) return fail(ctx, MSM_AMD_INPUT_ERROR, "n differs from the number of points the tables hold");
+  }
+  const uint32_t c = tb ? tb->c : (ctx->forced_window ? ctx->forced_window : auto_window(n));
+  const Plan p = tb ? make_plan(n, c, tb->W) : make_plan(n, c);
   *plan_out = p;
   int rc;
   if ((rc = slot_prepare(ctx, slot, p.partial_count))) return rc;
-  if ((rc = ensure(ctx, w.digits, (size_t)p.W * n * sizeof(uint16_t)))) return rc;
+  n = p.n;   // from here on: sorted entries per window (= points, or W_digits * points with tables)
+  if ((rc = ensure(ctx, w.digits, (size_t)p.W * n * (p.wide_digits ? sizeof(uint32_t) : sizeof(uint16_t))))) return rc;
   if ((rc = ensure(ctx, w.coarse_cnt, (size_t)p.W * p.Q * (1u << p.hb) * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.region_start, (size_t)p.W * ((1u << p.hb) + 1) * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.tmp_idx, (size_t)p.W * n * sizeof(uint32_t)))) return rc;
@@ -389,19 +432,19 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   if ((rc = ensure(ctx, w.bsize, p.total_buckets * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.bstart, p.total_buckets * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.istart, p.total_buckets * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, w.win_items, 1024 * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, w.win_items, (1024 + 2 * 1024) * sizeof(uint32_t)))) return rc;   // + tile_sums (<= 1024 tiles)
   if ((rc = ensure(ctx, w.size_bins, (size_t)(p.CH + 1) * ((p.total_buckets + p.front_threads - 1) / p.front_threads) *
                                          sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.sorted, (size_t)p.W * n * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.order, p.max_items * sizeof(uint2)))) return rc;
   if ((rc = ensure(ctx, w.multi_list, p.max_items * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.counters, sizeof(PlanCounters)))) return rc;
-  const bool prepared = point_layout == MSM_AMD_POINT_PREPARED;
+  const bool prepared = point_layout == MSM_AMD_POINT_PREPARED || tb != nullptr;
   if (!prepared && (rc = ensure(ctx, w.bases29, n * sizeof(AffPacked)))) return rc;
   if ((rc = ensure(ctx, w.buckets, p.total_buckets * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.item_partials, p.max_items * sizeof(PtI)))) return rc;
   SortBuffers sb{};
-  sb.digits = (uint16_t*)w.digits.p;
+  sb.digits = w.digits.p;
   sb.coarse_cnt = (uint32_t*)w.coarse_cnt.p;
   sb.region_start = (uint32_t*)w.region_start.p;
   sb.tmp_idx = (uint32_t*)w.tmp_idx.p;
@@ -410,6 +453,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   sb.bucket_start = (uint32_t*)w.bstart.p;
   sb.item_start = (uint32_t*)w.istart.p;
   sb.win_items = (uint32_t*)w.win_items.p;
+  sb.tile_sums = (uint2*)((uint32_t*)w.win_items.p + 1024);   // second half of the same small buffer
   sb.size_bins = (uint32_t*)w.size_bins.p;
   sb.sorted = (uint32_t*)w.sorted.p;
   sb.order = (uint2*)w.order.p;
@@ -422,7 +466,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   //   main   : accumulate of instance i                                      -- needs front(i)
   //   reduce : combine + window reduction + copy of instance i               -- needs main(i)
   hipStream_t fs = ctx->overlap_front ? ctx->front_stream : st;
-  hipStream_t rs = ctx->overlap_reduce ? ctx->reduce_stream : st;
+  hipStream_t rs = ctx->overlap_reduce ? ((ctx->alt_reduce && (ctx->seq++ & 1u)) ? ctx->reduce_stream2 : ctx->reduce_stream) : st;
   if (w.acc_pending && fs != st) {   // the previous accumulate in this workspace still reads its plan ...
     HIP_TRY(ctx, hipStreamWaitEvent(fs, w.acc_done, 0));
   }
@@ -434,9 +478,11 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   const u256* sc = nullptr;
   const Affine* pts = nullptr;
   int sc_mont = 0;
-  if ((rc = convert_inputs(ctx, w, fs, scalar_layout, point_layout, d_scalars, d_points, n, &sc, &sc_mont, &pts)))
+  if ((rc = convert_inputs(ctx, w, fs, scalar_layout, tb ? MSM_AMD_POINT_PREPARED : point_layout, d_scalars, d_points,
+                           p.n_scalars, &sc, &sc_mont, &pts)))
     return rc;
-  const AffPacked* bases = prepared ? (const AffPacked*)d_points : (const AffPacked*)w.bases29.p;
+  const AffPacked* bases = tb ? (const AffPacked*)tb->d_tables
+                              : (prepared ? (const AffPacked*)d_points : (const AffPacked*)w.bases29.p);
   if (!prepared) launch_convert_bases(fs, pts, p.n, (AffPacked*)w.bases29.p);   // external 8 x u32 -> packed internal domain
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_CONVERT], fs));
   launch_digits(fs, p, sc, sc_mont, sb.digits);
@@ -504,9 +550,9 @@ void accumulate_timings(msm_amd_ctx* ctx, InstanceSlot& s, const Plan& p, float 
   T.accumulate_kernel_ms += span(EV_ACC_K0, EV_ACC_K1) * inv;
   T.final_ms += final_ms * inv;
   T.total_gpu_ms += (ms[EV_CONVERT] + ms[EV_DIGITS] + ms[EV_SORT] + ms[EV_ACC] + ms[EV_REDUCE]) * inv;
-  T.n = p.n;
+  T.n = p.n_scalars;
   T.window_size = p.c;
-  T.num_windows = p.W;
+  T.num_windows = p.W_digits;
   T.reserved = (uint32_t)n_inst;
   PlanCounters pc;
   std::memcpy(&pc, s.h_partial + s.h_partial_cap, sizeof pc);
@@ -548,6 +594,8 @@ int submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, s
       (void)hipStreamSynchronize(ctx->front_stream);
       (void)hipStreamSynchronize(ctx->stream);
       (void)hipStreamSynchronize(ctx->reduce_stream);
+  (void)hipStreamSynchronize(ctx->reduce_stream2);
+      (void)hipStreamSynchronize(ctx->reduce_stream2);
       return rc;
     }
   }
@@ -591,7 +639,7 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
     return fail(ctx, MSM_AMD_INPUT_ERROR, "null argument or empty batch");
   const size_t pb = point_bytes(point_layout);
   if (pb == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown point layout");
-  if (point_layout == MSM_AMD_POINT_PREPARED)
+  if (point_layout == MSM_AMD_POINT_PREPARED || point_layout == MSM_AMD_POINT_TABLES)
     return fail(ctx, MSM_AMD_INPUT_ERROR, "prepared bases live on the device: use msm_amd_msm_prepared");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   for (size_t i = 0; i < n_inst; ++i)
@@ -698,11 +746,13 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   ctx->device = device;
   if (const char* e = std::getenv("MSM_AMD_OVERLAP_REDUCE")) ctx->overlap_reduce = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSM_AMD_OVERLAP_FRONT")) ctx->overlap_front = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MSM_AMD_ALT_REDUCE")) ctx->alt_reduce = std::atoi(e) != 0;
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   // the short front-end / reduction kernels get priority over the long accumulate grid
   bool ok = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_least) == hipSuccess &&
             hipStreamCreateWithPriority(&ctx->reduce_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+            hipStreamCreateWithPriority(&ctx->reduce_stream2, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipStreamCreateWithPriority(&ctx->front_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
   for (int k = 0; ok && k < kWorkspaces; ++k)
     ok = hipEventCreateWithFlags(&ctx->ws[k].front_done, hipEventDisableTiming) == hipSuccess &&
@@ -718,6 +768,7 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
     std::fprintf(stderr, "msm_amd: %s\n", ctx->last_error.c_str());
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->reduce_stream);
+    (void)hipStreamDestroy(ctx->reduce_stream2);
     (void)hipStreamDestroy(ctx->front_stream);
     delete ctx;
     return rc;
@@ -755,6 +806,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->front_stream);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->reduce_stream);
+  (void)hipStreamSynchronize(ctx->reduce_stream2);
   for (int k = 0; k < kWorkspaces; ++k) {
     Workspace& w = ctx->ws[k];
     DeviceBuf* bufs[] = {&w.digits, &w.coarse_cnt, &w.region_start, &w.tmp_idx, &w.tmp_fine, &w.bsize, &w.bstart, &w.istart, &w.win_items, &w.size_bins, &w.sorted,
@@ -766,6 +818,11 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (w.acc_done) (void)hipEventDestroy(w.acc_done);
     if (w.reduce_done) (void)hipEventDestroy(w.reduce_done);
   }
+  for (msm_amd_tables* t : ctx->live_tables) {   // tables the caller did not free
+    (void)hipFree(t->d_tables);
+    delete t;
+  }
+  ctx->live_tables.clear();
   DeviceBuf* sbufs[] = {&ctx->scratch_a, &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_b2, &ctx->scratch_c2};
   for (DeviceBuf* b : sbufs)
     if (b->p) (void)hipFree(b->p);
@@ -777,6 +834,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   }
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->reduce_stream);
+  (void)hipStreamDestroy(ctx->reduce_stream2);
   (void)hipStreamDestroy(ctx->front_stream);
   delete ctx;
 }
@@ -971,6 +1029,132 @@ int msm_amd_bases_upload(msm_amd_ctx* ctx, int point_layout, const void* points,
   return MSM_AMD_OK;
 }
 
+// ---- precomputed window tables ------------------------------------------------------------
+static uint32_t auto_table_window(size_t n) {
+  // One bucket set serves all windows, so the window can grow until the 2^(c-1) buckets of the window reduction
+  // (2 full additions each) cost as much as the mixed additions they save.  Windows whose top digit is narrow are
+  // excluded: the n entries of the top window would all fall into its few slots (c = 19 leaves 7 bits for the top
+  // window of a 254-bit scalar: 2^20 entries in 128 buckets and in ONE region of the sort).
+  uint32_t best = 4;
+  double best_cost = 1e300;
+  for (uint32_t c = 4; c <= 21; ++c) {
+    const uint32_t W = kModulusBits / c + 1;
+    const uint32_t top = kModulusBits - (W - 1) * c;          // bits of the top window
+    if (top + 6 < c && c > 6) continue;                        // top window concentrated > 64-fold
+    if ((size_t)W * n > 0x7FFFFFFFull) continue;
+    const double cost = 9.5 * (double)W * (double)n + 27.0 * (double)((size_t)1 << (c - 1)) + 14.0 * (double)W * (double)n / 32.0;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = c;
+    }
+  }
+  return best;
+}
+
+static int tables_build_locked(msm_amd_ctx* ctx, int point_layout, const void* d_points, size_t n, uint32_t window_size,
+                               msm_amd_tables** out) {
+  const uint32_t c = window_size ? window_size : auto_table_window(n);
+  if (c < 4 || c > 21) return fail(ctx, MSM_AMD_INPUT_ERROR, "table window_size must be 0 (auto) or 4..21");
+  const uint32_t W = kModulusBits / c + 1;
+  if ((size_t)W * n > 0x7FFFFFFFull) return fail(ctx, MSM_AMD_INPUT_ERROR, "windows * n must stay below 2^31");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());   // a set-up step: the conversion scratch of workspace 0 must be idle
+  hipStream_t st = ctx->stream;
+  const u256* sc = nullptr;
+  const Affine* pts = nullptr;
+  int sc_mont = 0, rc;
+  if (point_layout == MSM_AMD_POINT_PREPARED || point_layout == MSM_AMD_POINT_TABLES)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "tables are built from one of the host point layouts");
+  if ((rc = convert_inputs(ctx, ctx->ws[0], st, MSM_AMD_SCALAR_CANON_LE, point_layout, d_points, d_points, n, &sc,
+                           &sc_mont, &pts)))
+    return rc;
+  void* d_tab = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d_tab, (size_t)W * n * sizeof(AffPacked)));
+  launch_build_tables(st, pts, (uint32_t)n, c, W, (AffPacked*)d_tab);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    (void)hipFree(d_tab);
+    HIP_TRY(ctx, e);
+  }
+  auto* t = new msm_amd_tables();
+  t->n = n;
+  t->c = c;
+  t->W = W;
+  t->d_tables = d_tab;
+  ctx->live_tables.push_back(t);
+  *out = t;
+  return MSM_AMD_OK;
+}
+
+int msm_amd_tables_build_device(msm_amd_ctx* ctx, int point_layout, const void* d_points, size_t n, uint32_t window_size,
+                                msm_amd_tables** out) {
+  if (!ctx || !d_points || !out || n == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "bad tables_build arguments");
+  *out = nullptr;
+  if (point_bytes(point_layout) == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown point layout");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  return tables_build_locked(ctx, point_layout, d_points, n, window_size, out);
+}
+
+int msm_amd_tables_build(msm_amd_ctx* ctx, int point_layout, const void* points, size_t n, uint32_t window_size,
+                         msm_amd_tables** out) {
+  if (!ctx || !points || !out || n == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "bad tables_build arguments");
+  *out = nullptr;
+  const size_t pb = point_bytes(point_layout);
+  if (pb == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown point layout");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->scratch_c, n * pb))) return rc;
+  HIP_TRY(ctx, hipMemcpy(ctx->scratch_c.p, points, n * pb, hipMemcpyHostToDevice));
+  return tables_build_locked(ctx, point_layout, ctx->scratch_c.p, n, window_size, out);
+}
+
+int msm_amd_tables_info(msm_amd_ctx* ctx, const msm_amd_tables* tables, size_t* n, uint32_t* window_size,
+                        uint32_t* num_windows, size_t* device_bytes) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  const msm_amd_tables* t = find_tables(ctx, tables);
+  if (!t) return fail(ctx, MSM_AMD_INPUT_ERROR, "not a table handle of this ctx");
+  if (n) *n = t->n;
+  if (window_size) *window_size = t->c;
+  if (num_windows) *num_windows = t->W;
+  if (device_bytes) *device_bytes = (size_t)t->W * t->n * sizeof(AffPacked);
+  return MSM_AMD_OK;
+}
+
+int msm_amd_tables_free(msm_amd_ctx* ctx, msm_amd_tables* tables) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  auto it = std::find(ctx->live_tables.begin(), ctx->live_tables.end(), tables);
+  if (it == ctx->live_tables.end()) return fail(ctx, MSM_AMD_INPUT_ERROR, "not a table handle of this ctx");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  ctx->live_tables.erase(it);
+  (void)hipFree(tables->d_tables);
+  delete tables;
+  return MSM_AMD_OK;
+}
+
+int msm_amd_msm_tables(msm_amd_ctx* ctx, const msm_amd_tables* tables, int scalar_layout, const void* scalars,
+                       void* out96) {
+  if (!ctx || !tables || !scalars || !out96) return fail(ctx, MSM_AMD_INPUT_ERROR, "bad msm_tables arguments");
+  if (scalar_layout < MSM_AMD_SCALAR_MONT_LE || scalar_layout > MSM_AMD_SCALAR_CANON_BE32)
+    return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown scalar layout");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  const msm_amd_tables* t = find_tables(ctx, tables);
+  if (!t) return fail(ctx, MSM_AMD_INPUT_ERROR, "not a table handle of this ctx");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  const size_t n = t->n;
+  if ((rc = ensure(ctx, ctx->scratch_b, n * 32))) return rc;
+  hipStream_t up = ctx->overlap_front ? ctx->front_stream : ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars, n * 32, hipMemcpyHostToDevice, up));
+  const void* ds = ctx->scratch_b.p;
+  const void* dp = tables;
+  return run_batch_device(ctx, scalar_layout, MSM_AMD_POINT_TABLES, 1, &ds, &dp, &n, out96);
+}
+
 int msm_amd_msm_prepared(msm_amd_ctx* ctx, int scalar_layout, const void* scalars, const void* d_prepared, size_t n,
                          void* out96) {
   if (!ctx || !scalars || !d_prepared || !out96 || n == 0)
@@ -1031,6 +1215,7 @@ int msm_amd_synchronize(msm_amd_ctx* ctx) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->front_stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->reduce_stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->reduce_stream2));
   return MSM_AMD_OK;
 }
 

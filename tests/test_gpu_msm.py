@@ -232,3 +232,56 @@ def test_one_ctx_from_two_threads(cfg, msm_pkg):
         t.join()
     assert not errors
     assert len(results) == 20 and all(r == want for r in results)
+
+
+@pytest.mark.parametrize("n,c", [(700, 0), (700, 7), (700, 15), (700, 16), (3000, 19), (64, 21), (33, 4)])
+def test_precomputed_window_tables_match_the_per_call_path(cfg, msm_pkg, n, c):
+    """tables 2^(c w) P_i built once; every window then shares one bucket set (u16 digits up to
+    c = 15, u32 digits above).  Same bytes as the per-call pipeline for several scalar sets, incl. an identity base,
+    repeated points and scalars whose signed digits carry through every window."""
+    pts, sc = small_instance(5000 + n + c, n)
+    pts[3] = None
+    pts[7] = pts[8]
+    sc[0], sc[1], sc[2] = o.R_ORDER - 1, (1 << 253) - 1, 0
+    sc[7] = sc[8]
+    sb, pb = h2c_instance_bytes(pts, sc)
+    want = msm_pkg.gpu_msm_h2c(sb, pb, cfg)
+    assert o.decode_jacobian_mont_le(want) == _expect(pts, sc)
+    t = cfg.tables_build(pb, n, window_size=c)
+    try:
+        info = cfg.tables_info(t)
+        assert info["n"] == n and info["num_windows"] == 254 // info["window_size"] + 1
+        assert info["device_bytes"] == 64 * n * info["num_windows"]
+        if c:
+            assert info["window_size"] == c
+        assert cfg.msm_tables(sb, t) == want
+        sc2 = [(k * 3 + 5) % o.R_ORDER for k in sc]
+        sb2, _ = h2c_instance_bytes(pts, sc2)
+        d_sc = cfg.alloc(len(sb2))
+        cfg.to_device(d_sc, sb2)
+        (got,) = cfg.msm_batch_device([d_sc], [t], [n], point_layout=msm_pkg.POINT_TABLES)
+        cfg.free(d_sc)
+        assert got == msm_pkg.gpu_msm_h2c(sb2, pb, cfg)
+    finally:
+        cfg.tables_free(t)
+
+
+def test_precomputed_tables_errors(cfg, msm_pkg):
+    pts, sc = small_instance(91, 50)
+    sb, pb = h2c_instance_bytes(pts, sc)
+    with pytest.raises(msm_pkg.MsmError):
+        cfg.tables_build(pb, 50, window_size=22)
+    t = cfg.tables_build(pb, 50)
+    try:
+        d_sc = cfg.alloc(len(sb))
+        cfg.to_device(d_sc, sb)
+        with pytest.raises(msm_pkg.MsmError) as e:                       # n differs from the table's
+            cfg.msm_batch_device([d_sc], [t], [49], point_layout=msm_pkg.POINT_TABLES)
+        assert e.value.status == msm_pkg.INPUT_ERROR
+        with pytest.raises(msm_pkg.MsmError):                            # a device pointer is not a table handle
+            cfg.msm_batch_device([d_sc], [d_sc], [50], point_layout=msm_pkg.POINT_TABLES)
+        cfg.free(d_sc)
+    finally:
+        cfg.tables_free(t)
+    with pytest.raises(msm_pkg.MsmError):
+        cfg.tables_free(t)                                               # already freed
