@@ -25,7 +25,8 @@ struct Plan {
   uint32_t front_threads;     // workgroup size of the sort / planning kernels (256..1024)
   uint32_t CH;                // accumulate: max points per work item (bucket chunk)
   uint32_t nseg, K;           // reduce: segments per window, bits of segment index (lb - 3)
-  uint32_t tree_threads, tree_parts;   // reduce_tree: threads per workgroup, slices per (sum, window)
+  uint32_t tree_parts;        // reduce_tree: one-wave slices per (sum, window) (two-level form)
+  uint32_t tree_wide_threads; // != 0: single-level form with this many threads per (sum, window) instead
   size_t total_buckets, total_segs, partial_count, max_items;
 };
 
@@ -71,7 +72,8 @@ void launch_combine(hipStream_t st, const Plan& p, const SortBuffers& b, PtI* bu
 
 // k_reduce.hip
 int reduce_set_attributes(const char** failed);
-void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, PtI* S, PtI* T, Jacobian* partial);
+void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, PtI* S, PtI* T, PtI* tree_tmp,
+                   Jacobian* partial);
 
 // k_misc.hip
 void launch_projective_to_affine(hipStream_t st, const Jacobian* in, uint32_t n, Affine* out);

@@ -54,7 +54,8 @@ struct InstanceSlot {
 // 1024-thread sort workgroups of the other stream from being placed at all.)
 struct Workspace {
   DeviceBuf digits, coarse_cnt, region_start, tmp_idx, tmp_fine, bsize, bstart, istart, win_items, size_bins, sorted,
-      order, multi_list, counters, bases29, buckets, item_partials, S, T, partial, conv_scalars, conv_points, conv_tmp;
+      order, multi_list, counters, bases29, buckets, item_partials, S, T, tree_tmp, partial, conv_scalars, conv_points,
+      conv_tmp;
   hipEvent_t front_done = nullptr;    // front stream: sorted indices / work items of this workspace are ready
   hipEvent_t acc_done = nullptr;      // main stream: buckets of this workspace are complete (incl. combine)
   hipEvent_t reduce_done = nullptr;   // reduce stream: buckets / partial of this workspace are free again
@@ -209,12 +210,18 @@ Plan make_plan(size_t n_scalars, uint32_t c, uint32_t windows = 0) {
   p.total_buckets = (size_t)p.W * p.nb;
   p.total_segs = (size_t)p.W * p.nseg;
   p.max_items = p.total_buckets + ((size_t)p.W * n) / ch + 1;
-  uint32_t t = 64;
-  while (t < 512 && t < std::max(1u, p.nseg / 2)) t <<= 1;
-  p.tree_threads = t;
-  p.tree_parts = 1;   // at most 4 segments per thread and sum (nseg is a power of two, so parts divides it)
-  while (p.tree_parts < 64 && (p.nseg / 2) / p.tree_parts > 4 * t) p.tree_parts <<= 1;
-  p.partial_count = (size_t)p.W * (p.K + 2) * p.tree_parts;
+  // tree sums: one 64..512-thread workgroup per (sum, window) while that means at most 4 segments per thread
+  // (every per-call plan), else two levels of one-wave slices (the single long window of the table pipeline)
+  p.tree_parts = 1;
+  p.tree_wide_threads = 0;
+  if (p.nseg / 2 <= 4 * 512) {
+    uint32_t t = 64;
+    while (t < 512 && t < std::max(1u, p.nseg / 2)) t <<= 1;
+    p.tree_wide_threads = t;
+  } else {
+    while ((p.nseg / 2) / p.tree_parts > 4 * 64) p.tree_parts <<= 1;
+  }
+  p.partial_count = (size_t)p.W * (p.K + 2);
   return p;
 }
 
@@ -229,10 +236,15 @@ Plan make_reduce_plan(uint32_t lb, uint32_t W) {
   p.K = lb - kSegLog;
   p.total_buckets = (size_t)p.W * p.nb;
   p.total_segs = (size_t)p.W * p.nseg;
-  uint32_t t = 64;
-  while (t < 512 && t < std::max(1u, p.nseg / 2)) t <<= 1;
-  p.tree_threads = t;
   p.tree_parts = 1;
+  p.tree_wide_threads = 0;
+  if (p.nseg / 2 <= 4 * 512) {
+    uint32_t t = 64;
+    while (t < 512 && t < std::max(1u, p.nseg / 2)) t <<= 1;
+    p.tree_wide_threads = t;
+  } else {
+    while ((p.nseg / 2) / p.tree_parts > 4 * 64) p.tree_parts <<= 1;
+  }
   p.partial_count = (size_t)p.W * (p.K + 2);
   return p;
 }
@@ -276,14 +288,11 @@ Jacobian normalise(const Jacobian& p) {
 Jacobian host_combine(const Jacobian* partial, const Plan& p) {
   const uint32_t top = p.c * p.W;   // exclusive upper bound of bit positions
   std::vector<std::vector<const Jacobian*>> at(top + 1);
-  const uint32_t parts = std::max(1u, p.tree_parts);
   for (uint32_t w = 0; w < p.W; ++w) {
-    const Jacobian* pw = partial + (size_t)w * (p.K + 2) * parts;   // [K + 2][parts]
-    for (uint32_t part = 0; part < parts; ++part) {
-      at[p.c * w].push_back(&pw[(size_t)p.K * parts + part]);
-      at[p.c * w].push_back(&pw[(size_t)(p.K + 1) * parts + part]);
-      for (uint32_t k = 0; k < p.K; ++k) at[p.c * w + kSegLog + k].push_back(&pw[(size_t)k * parts + part]);
-    }
+    const Jacobian* pw = partial + (size_t)w * (p.K + 2);
+    at[p.c * w].push_back(&pw[p.K]);
+    at[p.c * w].push_back(&pw[p.K + 1]);
+    for (uint32_t k = 0; k < p.K; ++k) at[p.c * w + kSegLog + k].push_back(&pw[k]);
   }
   Jacobian acc = jac_identity();
   for (int pos = (int)top; pos >= 0; --pos) {
@@ -396,8 +405,9 @@ int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, hipStream_t st, const Plan& p
   int rc;
   if ((rc = ensure(ctx, w.S, p.total_segs * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.T, p.total_segs * sizeof(PtI)))) return rc;
+  if ((rc = ensure(ctx, w.tree_tmp, p.partial_count * p.tree_parts * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.partial, p.partial_count * sizeof(Jacobian)))) return rc;
-  launch_reduce(st, p, buckets, (PtI*)w.S.p, (PtI*)w.T.p, (Jacobian*)w.partial.p);
+  launch_reduce(st, p, buckets, (PtI*)w.S.p, (PtI*)w.T.p, (PtI*)w.tree_tmp.p, (Jacobian*)w.partial.p);
   HIP_TRY(ctx, hipGetLastError());
   return MSM_AMD_OK;
 }
@@ -811,7 +821,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     Workspace& w = ctx->ws[k];
     DeviceBuf* bufs[] = {&w.digits, &w.coarse_cnt, &w.region_start, &w.tmp_idx, &w.tmp_fine, &w.bsize, &w.bstart, &w.istart, &w.win_items, &w.size_bins, &w.sorted,
                          &w.order, &w.multi_list, &w.counters, &w.bases29, &w.buckets, &w.item_partials, &w.S, &w.T,
-                         &w.partial, &w.conv_scalars, &w.conv_points, &w.conv_tmp};
+                         &w.tree_tmp, &w.partial, &w.conv_scalars, &w.conv_points, &w.conv_tmp};
     for (DeviceBuf* b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (w.front_done) (void)hipEventDestroy(w.front_done);
