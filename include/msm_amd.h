@@ -92,7 +92,7 @@ const char* msm_amd_strerror(int status);
 /* Human-readable detail of the last failure on this ctx (empty string if none). */
 const char* msm_amd_last_error(const msm_amd_ctx* ctx);
 
-/* encode_instances' `window_size: Option<u32>` (msm.rs:130-141): 0 = automatic, else 3..15. */
+/* encode_instances' `window_size: Option<u32>` (msm.rs:130-141): 0 = automatic, else 3..17. */
 int msm_amd_set_window_size(msm_amd_ctx* ctx, uint32_t window_size);
 /* The automatic choice for n points (reference policy: 3 if n < 32 else 15, msm.rs:135-141;
  * this library: 3 if n < 32 else clamp(floor(log2 n) - 5, 4, 15), equal at n >= 2^20). */

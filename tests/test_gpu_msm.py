@@ -25,7 +25,7 @@ def test_gpu_msm_h2c_small(cfg, msm_pkg, n):
     assert z in (0, o.MONT_R % o.P)
 
 
-@pytest.mark.parametrize("c", [3, 4, 7, 8, 11, 13, 15])
+@pytest.mark.parametrize("c", [3, 4, 7, 8, 11, 13, 15, 16, 17])
 def test_window_sizes_agree(cfg, msm_pkg, c):
     pts, sc = small_instance(7, 300)
     sb, pb = h2c_instance_bytes(pts, sc)
@@ -125,7 +125,7 @@ def test_batch_and_errors(cfg, msm_pkg):
         cfg.msm(b"", b"", 0)
     assert ei.value.status == msm_pkg.INPUT_ERROR
     with pytest.raises(msm_pkg.MsmError):
-        cfg.set_window_size(16)
+        cfg.set_window_size(18)
 
 
 def test_device_generator_matches_oracle(cfg, msm_pkg):

@@ -36,7 +36,7 @@ def test_window_policy(msm_pkg):
     assert L.msm_amd_auto_window_size(1) == 3 and L.msm_amd_auto_window_size(31) == 3     # msm.rs:137-138
     assert L.msm_amd_auto_window_size(32) == 4
     assert L.msm_amd_auto_window_size(1 << 20) == 15                                      # msm.rs:140
-    assert L.msm_amd_auto_window_size(1 << 24) == 15
+    assert L.msm_amd_auto_window_size(1 << 22) == 15 and L.msm_amd_auto_window_size(1 << 24) == 17   # u32 digits
     ws = [L.msm_amd_auto_window_size(1 << k) for k in range(5, 25)]
     assert ws == sorted(ws)
 
