@@ -22,7 +22,8 @@
 //   reduce stream (k_accumulate.hip, k_reduce.hip)
 //   combine_small/big     sum the partials of split buckets into buckets
 //   reduce_seg_kernel     buckets -> S[W][nseg], T[W][nseg]   (running sums over segments of 8 slots)
-//   reduce_tree_kernel    S, T -> partial[W][K+2]  (plain sums + K bit-subset sums per window, external Jacobian)
+//   reduce_tree_*_kernel  S, T -> partial[W][K+2]  (plain sums + K bit-subset sums per window, external Jacobian;
+//                         one wide workgroup per sum, or two levels of one-wave workgroups for long windows)
 //   host                  Horner over the bit positions of the (K+2) * W partial points (msm_host.hip host_combine)
 //
 // This replaces the reference's prepare_buckets_indices / sort_buckets (CPU rayon sort!) /
