@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--log-size", type=int, default=20)
     ap.add_argument("--instances", type=int, default=5, help="instances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--window", type=int, default=0, help="force the window size (0 = the library's automatic choice)")
     ap.add_argument("--precomputed-tables", action="store_true",
                     help="NOT the headline: window tables 2^(c w) P precomputed once per set of bases (SURVEY §8f N4), "
                          "one bucket set, c = log2(n) - 1")
@@ -52,6 +53,8 @@ def main():
     m = importlib.import_module("metal-msm-gpu-acceleration_amd")
     mg = importlib.import_module("metal-msm-gpu-acceleration_amd.multi_gpu")
     cfg = m.setup_metal_state(local_rank)          # fails loudly without a gfx950 device
+    if args.window:
+        cfg.set_window_size(args.window)
     n = 1 << args.log_size
     inst = args.instances
     d_pts, d_sc = [], []
@@ -132,7 +135,10 @@ def main():
 
     # ---- roofline of the dominant kernel (bucket accumulation), per launch = one instance
     L = m.lib()
-    a3 = L.msm_amd_algorithmic_bytes(n, window, 1)
+    # algorithmic bytes = SURVEY.md section 8(d)'s per-unit figure: one MSM under the REFERENCE's window policy (3 below
+    # 32 points, else 15: msm.rs:137-141), whatever window this build picks for itself -- the job is the same
+    ref_window = 15 if n >= 32 else 3
+    a3 = L.msm_amd_algorithmic_bytes(n, ref_window, 1)
     acc_avg_ms = sum(acc_ms) / len(acc_ms)
     achieved = a3 / (acc_avg_ms * 1e-3) / 1e9
     traffic = None
@@ -145,7 +151,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": "accumulate_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": a3, "avg_launch_ms": round(acc_avg_ms, 4),
-                "whole_pipeline_GBps": round(L.msm_amd_algorithmic_bytes(n, window, 0) /
+                "whole_pipeline_GBps": round(L.msm_amd_algorithmic_bytes(n, ref_window, 0) /
                                              (sum(tot_ms) / len(tot_ms) * 1e-3) / 1e9, 2)}
 
     # ---- secondary roof (SURVEY 8d asks for it): the kernel is bound by quarter-rate 32-bit multiplies, not by HBM.

@@ -144,13 +144,18 @@ uint32_t floor_log2(size_t n) {
 }
 
 uint32_t auto_window(size_t n) {
+  // The reference uses 3 below 32 points and 15 from there on (msm.rs:137-141).  Measured on MI355X in batches
+  // (ms per MSM): 2^12 c=5 0.23 | 2^14 c=5 0.24 | 2^16 c=13 0.33 | 2^17..2^19 c=15 0.38 / 0.51 / 0.90 |
+  // 2^20 c=16 1.55 (15: 1.59) | 2^21 c=16 3.20 | 2^22 c=17 6.47 | 2^23 c=17 12.9.  Windows whose TOP digit is
+  // narrow are traps: the n entries of the top window then share a handful of buckets (c = 14 leaves 2 bits for
+  // the top window of a 254-bit scalar, c = 11 one bit: 2^17 points cost 1.2 ms with c = 10 or 11, 0.38 with 15).
   if (n < 32) return 3;   // msm.rs:137-138
   const uint32_t l = floor_log2(n);
-  const uint32_t c = l > 5 ? l - 5 : 0;
-  // the reference's own policy is 15 for every n >= 32 (msm.rs:140).  Measured: 16 / 17 (u32 digits, twice / four
-  // times the buckets) only pay from 2^23 points on (2^24: 30.2 instead of 31.8 ms; 2^22: no gain)
-  if (l >= 23) return kMaxWindow;
-  return std::min(15u, std::max(4u, c));
+  if (l <= 14) return 5;
+  if (l <= 16) return 13;
+  if (l <= 19) return 15;
+  if (l <= 21) return 16;   // u32 digits from here on
+  return kMaxWindow;
 }
 
 // `windows` = 0: the per-call pipeline (every signed-digit window owns a bucket set).  `windows` = W_digits > 0: the
