@@ -104,8 +104,8 @@ combine_small_kernel(const uint32_t* __restrict__ multi_list, PlanCounters* __re
                      const uint32_t* __restrict__ bucket_size, const uint32_t* __restrict__ item_start,
                      const uint32_t* __restrict__ win_base, uint32_t lb, uint32_t CH,
                      const PtI* __restrict__ partials, PtI* __restrict__ buckets, uint32_t* __restrict__ big_list) {
-  // the grid covers every possible split bucket (one lane each, launch_combine): no grid-stride loop, which keeps
-  // the kernel at <= 160 VGPRs so that its waves fit beside two accumulate waves of the next instance
+  // the grid covers every possible split bucket (one lane each, launch_combine): no grid-stride loop, fewer live
+  // registers (164 VGPRs)
   const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= counters->multi_count) return;
   const uint32_t b = multi_list[m];

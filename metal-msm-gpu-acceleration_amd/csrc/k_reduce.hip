@@ -15,8 +15,8 @@ reduce_seg_kernel(const PtI* __restrict__ buckets, uint32_t total_segs,
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= total_segs) return;
   // Two accumulators plus an operand and the temporaries of an addition need ~195 VGPRs; `sos` is parked in LDS
-  // while `sum` is updated, so the kernel stays at <= 160 and its waves fit beside two accumulate waves (176 VGPRs
-  // each) of the next instance instead of waiting for that grid to drain.
+  // while `sum` is updated, which brings the kernel to 176: a wave then fits on a SIMD as soon as ONE of the two
+  // resident accumulate waves (176 VGPRs each) retires, instead of needing 194 of the 512 registers.
   __shared__ PtI park[64];
   const PtI* X = buckets + (size_t)s * kSeg;
   PtI sum = pti_identity();
