@@ -89,6 +89,7 @@ struct msm_amd_ctx {
                                          // of an instance is a chain of four latency-bound kernels that is as long as
                                          // one accumulate, so two of them must be able to overlap
   bool alt_reduce = true;                // MSM_AMD_ALT_REDUCE=0: one reduce stream
+  bool low_occ_accumulate = true;        // 2-wave accumulate variant (set from overlap_front; MSM_AMD_LOW_OCC overrides)
   uint32_t seq = 0;
   hipStream_t front_stream = nullptr;    // side stream: conversion, digits, sort, work-item planning
   bool overlap_reduce = true;            // MSM_AMD_OVERLAP_REDUCE=0 puts the reduction on the main stream
@@ -520,7 +521,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   }
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC_S], st));
   launch_accumulate(st, p, bases, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p,
-                    ctx->overlap_front, slot.ev[EV_ACC_K0], slot.ev[EV_ACC_K1]);
+                    ctx->low_occ_accumulate, slot.ev[EV_ACC_K0], slot.ev[EV_ACC_K1]);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
   HIP_TRY(ctx, hipEventRecord(w.acc_done, st));
   w.acc_pending = true;
@@ -765,6 +766,8 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   if (const char* e = std::getenv("MSM_AMD_OVERLAP_REDUCE")) ctx->overlap_reduce = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSM_AMD_OVERLAP_FRONT")) ctx->overlap_front = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSM_AMD_ALT_REDUCE")) ctx->alt_reduce = std::atoi(e) != 0;
+  ctx->low_occ_accumulate = ctx->overlap_front;
+  if (const char* e = std::getenv("MSM_AMD_LOW_OCC")) ctx->low_occ_accumulate = std::atoi(e) != 0;
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   // the short front-end / reduction kernels get priority over the long accumulate grid
