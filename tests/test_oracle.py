@@ -17,6 +17,10 @@ def test_known_answers():
     assert o.scalar_mul(2, o.GEN) == (
         1368015179489954701390400359078579693043519447331113978918064868415326638035,
         9918110051302171585080402603319702774565515993150576347155970296011118125764)
+    # 3G = G + 2G (a generic addition, not a doubling): the alt_bn128 ecAdd/ecMul test vector
+    g3 = (3353031288059533942658390886683067124040920775575537747144343083137631628272,
+          19321533766552368860946552437480515441416830039777911637913418824951667761761)
+    assert o.aff_add(o.GEN, o.scalar_mul(2, o.GEN)) == g3 and o.scalar_mul(3, o.GEN) == g3
     assert o.to_affine(o.scalar_mul_jac(o.R_ORDER, o.to_jac(o.GEN))) is None          # r * G = O
     assert o.aff_add(o.GEN, o.aff_neg(o.GEN)) is None
     # constants hard-coded in the reference shader (fp_bn254.h.metal:25-46), big-endian limb order
