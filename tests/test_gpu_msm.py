@@ -285,3 +285,21 @@ def test_precomputed_tables_errors(cfg, msm_pkg):
         cfg.tables_free(t)
     with pytest.raises(msm_pkg.MsmError):
         cfg.tables_free(t)                                               # already freed
+
+
+def test_known_answers_without_the_oracle(cfg, msm_pkg):
+    """The GPU path against constants that do not come from this repository: 2G and 3G on alt_bn128 (the EIP-196
+    ecMul / ecAdd vectors).  Only the layout encoding is the oracle module's."""
+    g2 = (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+          9918110051302171585080402603319702774565515993150576347155970296011118125764)
+    g3 = (3353031288059533942658390886683067124040920775575537747144343083137631628272,
+          19321533766552368860946552437480515441416830039777911637913418824951667761761)
+    G = (1, 2)
+    sb, pb = h2c_instance_bytes([G], [2])
+    assert o.decode_jacobian_mont_le(msm_pkg.gpu_msm_h2c(sb, pb, cfg)) == g2
+    sb, pb = h2c_instance_bytes([G, g2], [1, 1])
+    assert o.decode_jacobian_mont_le(msm_pkg.gpu_msm_h2c(sb, pb, cfg)) == g3
+    sb, pb = h2c_instance_bytes([G, g2, g3], [o.R_ORDER - 3, o.R_ORDER - 3, 3])    # (r-3)(G + 2G) + 3(3G) = 0
+    assert o.decode_jacobian_mont_le(msm_pkg.gpu_msm_h2c(sb, pb, cfg)) is None
+    sb, pb = h2c_instance_bytes([G] * 3, [1, 1, 1])                                  # three equal points: 3G
+    assert o.decode_jacobian_mont_le(msm_pkg.gpu_msm_h2c(sb, pb, cfg)) == g3
