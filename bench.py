@@ -1,11 +1,18 @@
 """Headline benchmark: BN254 G1 MSM/s at log_size=20 (5 instances per GPU), see BASELINE.json.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (metal::msm::gpu_msm_h2c pipeline) over one batch of 5 synthetic
 2^20-point instances per GPU, inputs already resident in HBM (device generator).  Instances shard across
 ranks with no data-path collective; the per-instance results (96 B each) are all-gathered over RCCL.
 Prints ONE JSON line on rank 0.
+
+Launching.  One process per GPU.  `python bench.py --gpus N` with N > 1 and no RANK in the environment starts
+the N ranks itself as child processes BEFORE anything touches the GPU (multi_gpu.launch_local_ranks; the parent
+only waits and forwards the exit code).  Under `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N` the ranks are already there (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment).  Either way
+WORLD_SIZE must equal --gpus and every rank needs its own visible GPU, otherwise the run fails loudly instead of
+printing a line for fewer GPUs.  N = 1 goes through the same RCCL path (a one-rank process group).
 """
 import argparse
 import importlib
@@ -16,9 +23,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+PKG = "metal-msm-gpu-acceleration_amd"
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -26,32 +34,71 @@ def main():
     ap.add_argument("--log-size", type=int, default=20)
     ap.add_argument("--instances", type=int, default=5, help="instances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the drop-in-caller figures (host slices, lone calls)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     ap.add_argument("--window", type=int, default=0, help="force the window size (0 = the library's automatic choice)")
     ap.add_argument("--precomputed-tables", action="store_true",
                     help="NOT the headline: window tables 2^(c w) P precomputed once per set of bases (SURVEY §8f N4), "
-                         "one bucket set, c = log2(n) - 1")
+                         "one bucket set")
     ap.add_argument("--table-window", type=int, default=0, help="window bits of --precomputed-tables (0 = automatic)")
     ap.add_argument("--persistent-bases", action="store_true",
                     help="NOT the headline: bases converted once and kept resident (SURVEY §8f N4); the default "
                          "re-converts them inside every MSM like the reference does (msm.rs:152-153)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def resolve_world(args, environ):
+    """(rank, local_rank, world, must_launch) from --gpus and the environment; raises SystemExit on a mislaunch.
+    No torch, no GPU: this runs before anything else."""
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "RANK" in environ:
+        world = int(environ.get("WORLD_SIZE", "1"))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report "
+                             f"a line for a different number of GPUs")
+        return int(environ["RANK"]), int(environ.get("LOCAL_RANK", environ["RANK"])), world, False
+    return 0, 0, args.gpus, args.gpus > 1
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    rank, local_rank, world, must_launch = resolve_world(args, os.environ)
+    mg = importlib.import_module(PKG + ".multi_gpu")
+    if must_launch:
+        # N ranks as children, started before this process has imported torch or touched HIP
+        rc = mg.launch_local_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + argv)
+        if rc != 0:
+            print(f"bench.py: a rank failed (exit {rc}); no result line", file=sys.stderr)
+        raise SystemExit(rc)
+    if "RANK" not in os.environ:            # N = 1: same RCCL path, a process group of one
+        os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(mg.free_port()))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or "RANK" in os.environ:      # under torch.distributed.run (also with one rank)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    visible = torch.cuda.device_count()     # does not initialise the GPU
+    if visible <= local_rank or visible < world:
+        raise SystemExit(f"bench.py: rank {rank} of {world} needs GPU {local_rank} but only {visible} GPU(s) are "
+                         f"visible: --gpus {world} cannot run here")
+    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" IS RCCL on ROCm
 
-    m = importlib.import_module("metal-msm-gpu-acceleration_amd")
-    mg = importlib.import_module("metal-msm-gpu-acceleration_amd.multi_gpu")
+    m = importlib.import_module(PKG)
     cfg = m.setup_metal_state(local_rank)          # fails loudly without a gfx950 device
     if args.window:
         cfg.set_window_size(args.window)
@@ -62,33 +109,28 @@ def main():
         dp, ds = cfg.generate_instance(mg.instance_seed(g), n, True)
         d_pts.append(dp)
         d_sc.append(ds)
+    raw_pts = list(d_pts)
     ns = [n] * inst
     point_layout = m.POINT_H2C_AFFINE
     tables = []
     if args.precomputed_tables:
         tables = [cfg.tables_build_device(dp, n, window_size=args.table_window) for dp in d_pts]
-        for dp in d_pts:
-            cfg.free(dp)
         d_pts = tables
         point_layout = m.POINT_TABLES
     elif args.persistent_bases:
-        raw, d_pts = d_pts, [cfg.bases_prepare_device(dp, n) for dp in d_pts]
-        for dp in raw:
-            cfg.free(dp)
+        d_pts = [cfg.bases_prepare_device(dp, n) for dp in d_pts]
         point_layout = m.POINT_PREPARED
 
-    gatherer = mg.ResultGatherer(dist, dev, inst) if dist is not None else None
+    gatherer = mg.ResultGatherer(dist, dev, inst)
 
     def finish(handle):
         outs = cfg.wait_batch(handle)                    # host Horner pass of the batch
-        if gatherer is not None:                         # RCCL gather of per-instance results over xGMI
-            gatherer.gather(outs)                        # (enqueued; completes before the closing barrier)
-        t = cfg.timings()                                # hipEvent times on the library's own streams
+        gatherer.gather(outs)                            # RCCL gather of per-instance results over xGMI
+        t = cfg.timings()                                # (enqueued; completes before the closing barrier)
         return outs, t
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
         cfg.synchronize()
 
@@ -123,13 +165,20 @@ def main():
     outs = run_steps(args.steps, record)
     barrier()
     elapsed = time.perf_counter() - t0
-    if gatherer is not None:
-        allr = gatherer.fetch()                          # every rank holds every instance's result
-        assert allr[rank * inst:(rank + 1) * inst] == outs, "gathered results differ from the local ones"
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+
+    # ---- what came back over RCCL: every rank's results, and which ranks answered
+    allr = gatherer.fetch()                              # every rank holds every instance's result
+    if allr[rank * inst:(rank + 1) * inst] != outs:
+        raise SystemExit(f"rank {rank}: gathered results differ from the local ones")
+    ids = torch.full((1,), rank, dtype=torch.int32, device=dev)
+    seen = torch.empty(world, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(seen, ids)
+    ranks_seen = len(set(int(x) for x in seen.cpu().tolist()))
+    te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(te, op=dist.ReduceOp.MAX)
+    elapsed = float(te.item())
+    if ranks_seen != world or len(allr) != world * inst or any(r == bytes(96) for r in allr):
+        raise SystemExit(f"bench.py: only {ranks_seen} of {world} ranks answered the RCCL gather")
     tm = cfg.timings()
     window = tm.window_size
 
@@ -141,16 +190,25 @@ def main():
     a3 = L.msm_amd_algorithmic_bytes(n, ref_window, 1)
     acc_avg_ms = sum(acc_ms) / len(acc_ms)
     achieved = a3 / (acc_avg_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_src = None, None
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tf):
         try:
             traffic = json.load(open(tf)).get(f"accumulate_log{args.log_size}_bytes_per_launch")
+            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command, " \
+                          "2*FETCH_SIZE + WRITE_SIZE per launch; not measured by this process)"
         except Exception:
             traffic = None
+    # the kernel's OWN bytes (its window, 4-byte sorted entries, 64-byte packed bases, 144-byte XYZZ buckets)
+    own = (4 + 64) * n * tm.num_windows + 144 * tm.num_windows * (1 << max(window - 1, 3))
     roofline = {"bound": "hbm", "kernel": "accumulate_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": a3, "avg_launch_ms": round(acc_avg_ms, 4),
+                "own_layout": {"bytes_per_launch": own, "achieved": round(own / (acc_avg_ms * 1e-3) / 1e9, 2),
+                               "frac": round(own / (acc_avg_ms * 1e-3) / 8e12, 5),
+                               "note": f"this build's window {window}: (4 B sorted entry + 64 B packed base) per "
+                                       f"point and window + 144 B per XYZZ bucket"},
                 "whole_pipeline_GBps": round(L.msm_amd_algorithmic_bytes(n, ref_window, 0) /
                                              (sum(tot_ms) / len(tot_ms) * 1e-3) / 1e9, 2)}
 
@@ -167,33 +225,47 @@ def main():
             "work_items": int(items)}
     roofline["secondary"] = valu
 
-    # ---- CPU baseline (rank 0, single-GPU run only): the oracle's restatement of halo2curves msm_best
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- parity on every rank + CPU baseline (rank 0, single-GPU run only)
+    cpu, parity_ok, extras = None, True, None
+    if not args.no_cpu_baseline:
         from oracle import bn254_ref as o
         from oracle import c_oracle as co
-        cores = min(16, co.default_threads())
-        h_pts = [cfg.to_host(d_pts[j], 64 * n) for j in range(inst)]
+        cores_all = co.default_threads()
+        h_pts = [cfg.to_host(raw_pts[j], 64 * n) for j in range(inst)]
         h_sc = [cfg.to_host(d_sc[j], 32 * n) for j in range(inst)]
-        t_cpu0 = time.perf_counter()
-        done = 0
-        cpu_outs = []
-        while True:
+        if world == 1:
+            cores = cores_all                            # every core the node gives this process
+            t_cpu0 = time.perf_counter()
+            done, cpu_outs = 0, []
+            while True:
+                for j in range(inst):
+                    r = co.msm_best(h_sc[j], h_pts[j], n, cores)
+                    if done < inst:
+                        cpu_outs.append(r)
+                    done += 1
+                if time.perf_counter() - t_cpu0 > args.cpu_seconds or done >= 8 * inst:
+                    break
+            t_cpu = time.perf_counter() - t_cpu0
+            for j in range(inst):          # parity gate: bit-exact canonical affine result
+                if o.decode_jacobian_mont_le(outs[j]) != o.decode_jacobian_mont_le(cpu_outs[j]):
+                    raise SystemExit(f"PARITY FAILURE: instance {j} GPU != CPU")
+            cpu = {"value": round(done / t_cpu, 4), "unit": "MSM/s", "cores": cores, "cpu_model": cpu_model(),
+                   "kind": "port", "algorithm": co.MSM_BEST_ALGORITHM,
+                   "sample": f"{done} MSMs of 2^{args.log_size} points (the bench's own {inst} instances, "
+                             f"{done // inst} pass(es)) in {t_cpu:.1f} s, oracle_msm_best = C restatement of "
+                             f"halo2curves msm_best on {cores} threads", "bit_exact_vs_gpu": True}
+        else:
+            # every rank checks its OWN instances against the oracle (threads = its share of the host cores)
+            thr = max(1, cores_all // world)
             for j in range(inst):
-                r = co.msm_best(h_sc[j], h_pts[j], n, cores)
-                if done < inst:
-                    cpu_outs.append(r)
-                done += 1
-            if time.perf_counter() - t_cpu0 > 10.0 or done >= 4 * inst:
-                break
-        t_cpu = time.perf_counter() - t_cpu0
-        for j in range(inst):          # parity gate: bit-exact canonical affine result
-            if o.decode_jacobian_mont_le(outs[j]) != o.decode_jacobian_mont_le(cpu_outs[j]):
-                raise SystemExit(f"PARITY FAILURE: instance {j} GPU != CPU")
-        cpu = {"value": round(done / t_cpu, 4), "unit": "MSM/s", "cores": cores, "kind": "port",
-               "sample": f"{done} MSMs of 2^{args.log_size} points (the bench's own {inst} instances, "
-                         f"{done // inst} pass(es)), oracle_msm_best = C restatement of halo2curves msm_best, "
-                         f"{cores} threads", "bit_exact_vs_gpu": True}
+                if o.decode_jacobian_mont_le(outs[j]) != o.decode_jacobian_mont_le(co.msm_best(h_sc[j], h_pts[j], n, thr)):
+                    parity_ok = False
+        if rank == 0 and world == 1 and not args.no_extras and point_layout == m.POINT_H2C_AFFINE:
+            extras = drop_in_caller_figures(m, cfg, h_sc, h_pts, n, inst, outs)
+    okt = torch.tensor([1 if parity_ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    if int(okt.item()) != 1:
+        raise SystemExit("PARITY FAILURE on at least one rank (GPU != CPU oracle)")
 
     if rank == 0:
         total_msms = inst * world * args.steps
@@ -210,6 +282,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u32x8 (256-bit Montgomery integer)",
             "data": "synthetic",
+            "rccl_ranks_seen": ranks_seen,
+            "parity": ("bit-exact vs the CPU oracle on every rank's own instances" if not args.no_cpu_baseline
+                       else "not checked in this run (--no-cpu-baseline)"),
             "config": {"workload": f"log_size={args.log_size}, {inst} instances per GPU, h2c BN254 G1 "
                                    f"(gpu_msm_h2c pipeline, window {window})",
                        "instances_per_gpu": inst, "log_size": args.log_size, "window_size": window,
@@ -224,20 +299,71 @@ def main():
                                  "accumulate_kernel": round(acc_avg_ms, 4),
                                  "reduce": round(sum(red_ms) / len(red_ms), 4),
                                  "host_final": round(sum(fin_ms) / len(fin_ms), 4),
-                                 "gpu_total": round(sum(tot_ms) / len(tot_ms), 4)},
+                                 "gpu_total_sum_of_stage_spans": round(sum(tot_ms) / len(tot_ms), 4)},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "drop_in_caller": extras,
         }
         print(json.dumps(line), flush=True)
     for j in range(inst):
         if tables:
             cfg.tables_free(d_pts[j])
-        else:
+        elif args.persistent_bases:
             cfg.free(d_pts[j])
+        cfg.free(raw_pts[j])
         cfg.free(d_sc[j])
     cfg.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
+
+
+def drop_in_caller_figures(m, cfg, h_sc, h_pts, n, inst, expect):
+    """What a caller of the reference API gets (never `value`): the reference's bench hands HOST slices to msm_best
+    (benches/msm_benchmark.rs:116-121), so upload over PCIe is inside these numbers."""
+    import statistics
+    res = {}
+    ns = [n] * inst
+    cfg.msm_batch(h_sc, h_pts, ns)                               # warm-up (workspace, registrations)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        outs = cfg.msm_batch(h_sc, h_pts, ns)
+    dt = time.perf_counter() - t0
+    if outs != expect:
+        raise SystemExit("PARITY FAILURE: host-slice batch differs from the device-resident results")
+    res["e2e_host_slices_MSM_per_s"] = round(inst * reps / dt, 2)
+    res["e2e_host_slices_note"] = (f"msm_amd_msm_batch on host buffers: {inst} x 2^{n.bit_length() - 1} points, 96 MiB "
+                                   f"per instance uploaded inside the timed region")
+
+    def lone(k):
+        sc, pt = h_sc[0][:32 * k], h_pts[0][:64 * k]
+        m.gpu_msm_h2c(sc, pt, cfg)
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            m.gpu_msm_h2c(sc, pt, cfg)
+            ts.append(time.perf_counter() - t0)
+        return round(statistics.median(ts) * 1e3, 3)
+
+    def lone_resident(k):
+        dp, ds = cfg.alloc(64 * k), cfg.alloc(32 * k)
+        cfg.to_device(dp, h_pts[0][:64 * k])
+        cfg.to_device(ds, h_sc[0][:32 * k])
+        cfg.msm_batch_device([ds], [dp], [k])
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            cfg.msm_batch_device([ds], [dp], [k])
+            ts.append(time.perf_counter() - t0)
+        cfg.free(dp)
+        cfg.free(ds)
+        return round(statistics.median(ts) * 1e3, 3)
+
+    res["single_call_ms"] = {"gpu_msm_h2c_host_2^20": lone(min(n, 1 << 20)),
+                             "gpu_msm_h2c_host_2^18": lone(min(n, 1 << 18)),
+                             "resident_2^20": lone_resident(min(n, 1 << 20)),
+                             "resident_2^18": lone_resident(min(n, 1 << 18)),
+                             "note": "median wall time of ONE blocking call, nothing else in flight"}
+    return res
 
 
 if __name__ == "__main__":

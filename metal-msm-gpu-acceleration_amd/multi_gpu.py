@@ -24,6 +24,71 @@ def instance_seed(global_instance: int) -> int:
     return SEED_BASE + global_instance
 
 
+def rank_environments(nproc: int, master_port: int, base_env=None, master_addr: str = "127.0.0.1"):
+    """The N child environments of a one-node launch, one per GPU: RANK / LOCAL_RANK / WORLD_SIZE /
+    LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT on top of `base_env` (default: this process's environment) --
+    what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would hand its workers."""
+    if nproc < 1:
+        raise ValueError("nproc must be >= 1")
+    import os
+    base = dict(os.environ if base_env is None else base_env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    envs = []
+    for r in range(nproc):
+        e = dict(base)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nproc), "LOCAL_WORLD_SIZE": str(nproc),
+                  "MASTER_ADDR": master_addr, "MASTER_PORT": str(master_port)})
+        envs.append(e)
+    return envs
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_local_ranks(nproc: int, argv, master_port: int = 0, base_env=None, timeout=None) -> int:
+    """Start `nproc` worker processes (`argv` = full command line, e.g. [sys.executable, "bench.py", ...]), one per
+    GPU, and wait for them.  The caller must NOT have touched the GPU: workers are plain children (subprocess), the
+    parent is never replaced.  Rank 0 inherits stdout (it prints the result line).  Returns 0 only when EVERY rank
+    exited 0; when one rank fails the others are terminated (a rank that died would leave the rest in a collective
+    forever) and the first non-zero code is returned."""
+    import subprocess
+    import time
+    envs = rank_environments(nproc, master_port or free_port(), base_env)
+    procs = [subprocess.Popen(list(argv), env=e) for e in envs]
+    deadline = None if timeout is None else time.monotonic() + timeout
+    rc = 0
+    try:
+        pending = set(range(nproc))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+            if rc != 0 or (deadline is not None and time.monotonic() > deadline):
+                if rc == 0:
+                    rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:                       # exact PIDs we started, nothing by pattern
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc
+
+
 def all_gather_results(local_results, dist=None, device=None):
     """All-gather the per-instance 96-byte results of every rank; returns world*per_rank byte strings in
     global instance order.  `dist` is torch.distributed (already initialised) or None for one process."""
@@ -47,32 +112,60 @@ class ResultGatherer:
     """Per-step all-gather of the 96-byte results without a host synchronisation inside the step: staging and
     device tensors are allocated once, the copy to the device is asynchronous from pinned memory, the collective
     is enqueued on the backend's stream, and `fetch()` (one device->host copy) is only called when the caller
-    wants to look at the gathered bytes."""
+    wants to look at the gathered bytes.  The pinned staging buffer and its device twin exist DEPTH times and are
+    used round-robin; before a slot's host bytes are overwritten the event recorded after its previous
+    host->device copy is waited for, so a slow step can never gather the next step's bytes."""
+
+    DEPTH = 4
 
     def __init__(self, dist, device, per_rank):
         import torch
         self.dist, self.device, self.per_rank = dist, device, per_rank
         self.world = dist.get_world_size() if dist is not None else 1
         nbytes = RESULT_BYTES * per_rank
-        pin = device is not None and getattr(device, "type", "cpu") == "cuda"
-        self.stage = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pin)
+        self.cuda = device is not None and getattr(device, "type", "cpu") == "cuda"
         dev = device if device is not None else torch.device("cpu")
-        self.mine = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.stage = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=self.cuda) for _ in range(self.DEPTH)]
+        self.mine = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self.DEPTH)]
+        self.copied = [torch.cuda.Event() if self.cuda else None for _ in range(self.DEPTH)]
+        self.used = [False] * self.DEPTH
+        self.work = [None] * self.DEPTH
         self.all = torch.empty(self.world * nbytes, dtype=torch.uint8, device=dev)
+        self.turn = 0
+        self.steps = 0
 
     def gather(self, local_results):
         blob = b"".join(local_results)
         if len(blob) != RESULT_BYTES * self.per_rank:
             raise ValueError("expected %d results of 96 bytes" % self.per_rank)
         import torch
-        self.stage.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
-        self.mine.copy_(self.stage, non_blocking=True)
+        k = self.turn
+        self.turn = (k + 1) % self.DEPTH
+        if self.work[k] is not None:
+            self.work[k].wait()                   # the collective that last read this slot's device twin is ordered
+            self.work[k] = None                   # before what follows on the current stream (no host block on RCCL)
+        if self.cuda and self.used[k]:
+            self.copied[k].synchronize()          # the copy that last read this pinned slot has finished
+        self.stage[k].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        self.mine[k].copy_(self.stage[k], non_blocking=True)
+        if self.cuda:
+            self.copied[k].record()
+            self.used[k] = True
         if self.dist is not None:
-            self.dist.all_gather_into_tensor(self.all, self.mine)
+            self.work[k] = self.dist.all_gather_into_tensor(self.all, self.mine[k], async_op=True)
         else:
-            self.all.copy_(self.mine)
+            self.all.copy_(self.mine[k])
+        self.steps += 1
+
+    def drain(self):
+        """Order every outstanding collective before the current stream (call before reading `all`)."""
+        for k in range(self.DEPTH):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
 
     def fetch(self):
+        self.drain()
         raw = bytes(self.all.cpu().numpy().tobytes())
         return [raw[i * RESULT_BYTES:(i + 1) * RESULT_BYTES] for i in range(self.world * self.per_rank)]
 

@@ -9,6 +9,8 @@ from ctypes import c_char_p, c_int, c_size_t, c_uint32, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmsm_oracle.so")
 _LIB = None
+# what oracle_msm_best does (printed in bench.py's cpu_baseline)
+MSM_BEST_ALGORITHM = "chunk-parallel Pippenger, serial Jacobian buckets, signed digits"
 
 
 def build(force=False):
