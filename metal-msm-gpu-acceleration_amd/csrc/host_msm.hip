@@ -33,7 +33,14 @@ void msm_slice(const u256* scalars, int scalars_mont, const Affine* points, size
   const uint32_t W = 254 / c + 1;
   const uint32_t half = 1u << (c - 1);
   std::vector<u256> ks(n);
-  for (size_t i = 0; i < n; ++i) ks[i] = scalars_mont ? Fr::from_mont(scalars[i]) : scalars[i];
+  for (size_t i = 0; i < n; ++i) {
+    if (scalars_mont) {
+      ks[i] = Fr::from_mont(scalars[i]);
+    } else {   // raw canonical integers may exceed r: reduce (2^256 / r < 6), as digits_kernel does
+      ks[i] = scalars[i];
+      for (int k = 0; k < 5; ++k) ks[i] = Fr::reduce_once(ks[i]);
+    }
+  }
   // signed digits, window-major: digit[w][i]
   std::vector<int32_t> digits((size_t)W * n);
   for (size_t i = 0; i < n; ++i) {

@@ -152,11 +152,6 @@ combine_big_kernel(const uint32_t* __restrict__ big_list, const PlanCounters* __
   }
 }
 
-void launch_clear_buckets(hipStream_t st, const Plan& p, PtI* buckets) {
-  // empty buckets produce no work item: all-zero memory is the identity (Z = 0)
-  (void)hipMemsetAsync(buckets, 0, p.total_buckets * sizeof(PtI), st);
-}
-
 void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
                        PtI* partials, bool low_occupancy, hipEvent_t before_kernel, hipEvent_t after_kernel) {
   if (before_kernel) (void)hipEventRecord(before_kernel, st);

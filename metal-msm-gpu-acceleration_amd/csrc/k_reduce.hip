@@ -10,28 +10,36 @@ namespace msm_amd {
 // so that  sum_i (i+1) X[i] = sum_s (T[s] + S[s]) + 8 * sum_s s*S[s].   Replaces sum_reduction_partial
 // (msm.h.metal:319-461), whose combine step needs a scalar multiplication per merge.
 __global__ void __launch_bounds__(64)
-reduce_seg_kernel(const PtI* __restrict__ buckets, uint32_t total_segs,
+reduce_seg_kernel(const PtI* __restrict__ buckets, const uint32_t* __restrict__ bucket_size, uint32_t total_segs,
                   PtI* __restrict__ S, PtI* __restrict__ T) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= total_segs) return;
-  // Two accumulators plus an operand and the temporaries of an addition need ~195 VGPRs; `sos` is parked in LDS
-  // while `sum` is updated, which brings the kernel to 176: a wave then fits on a SIMD as soon as ONE of the two
-  // resident accumulate waves (176 VGPRs each) retires, instead of needing 194 of the 512 registers.
-  __shared__ PtI park[64];
-  const PtI* X = buckets + (size_t)s * kSeg;
-  PtI sum = pti_identity();
-  store_pti(&park[threadIdx.x], pti_identity());
+  // bucket_size != nullptr: an empty bucket (no work item ever wrote it) holds stale memory and counts as the
+  // identity -- the bucket matrix is not cleared per MSM.  The size is re-read per slot (an L2 hit) rather than
+  // kept as a mask: one more live register would push the kernel over the next allocation granule.
+  const bool sized = bucket_size != nullptr;   // wave-uniform
+  // Two accumulators plus an operand and the temporaries of an addition need ~195 VGPRs.  Both running values are
+  // parked in LDS between additions, so every addition has two operands that die in it (like the tree kernels:
+  // <= 160 VGPRs) and a wave fits into the registers two resident accumulate waves (2 x 176 of 512) leave free.
+  __shared__ PtI park_sum[64];
+  __shared__ PtI park_sos[64];
+  store_pti(&park_sum[threadIdx.x], pti_identity());
+  store_pti(&park_sos[threadIdx.x], pti_identity());
 #pragma unroll 1
-  for (int j = kSeg - 1; j >= 1; --j) {
-    sum = pti_add(sum, load_pti(&X[j]));
-    asm volatile("" ::: "memory");   // keep the LDS reload below the addition above (it is the point of parking)
-    const PtI sos = pti_add(load_pti(&park[threadIdx.x]), sum);
-    store_pti(&park[threadIdx.x], sos);
+  for (int j = kSeg - 1; j >= 0; --j) {
+    if (!sized || bucket_size[s * kSeg + j] != 0) {
+      const PtI sum = pti_add(load_pti(&park_sum[threadIdx.x]), load_pti(&buckets[s * kSeg + j]));
+      store_pti(&park_sum[threadIdx.x], sum);
+    }
+    asm volatile("" ::: "memory");   // keep the LDS reloads below the addition above (it is the point of parking)
+    if (j != 0) {
+      const PtI sos = pti_add(load_pti(&park_sos[threadIdx.x]), load_pti(&park_sum[threadIdx.x]));
+      store_pti(&park_sos[threadIdx.x], sos);
+    }
     asm volatile("" ::: "memory");
   }
-  sum = pti_add(sum, load_pti(&X[0]));
-  store_pti(&S[s], sum);
-  store_pti(&T[s], load_pti(&park[threadIdx.x]));
+  store_pti(&S[s], load_pti(&park_sum[threadIdx.x]));
+  store_pti(&T[s], load_pti(&park_sos[threadIdx.x]));
 }
 
 // Stage 4b: tree sums, in two levels of ONE-WAVE workgroups (64 lanes, <= 160 VGPRs): a workgroup of several
@@ -156,10 +164,10 @@ int reduce_set_attributes(const char** failed) {
   return 0;
 }
 
-void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, PtI* S, PtI* T, PtI* tree_tmp,
-                   Jacobian* partial) {
+void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, const uint32_t* bucket_size, PtI* S, PtI* T,
+                   PtI* tree_tmp, Jacobian* partial) {
   hipLaunchKernelGGL(reduce_seg_kernel, dim3((unsigned)((p.total_segs + 63) / 64)), dim3(64), 0, st, buckets,
-                     (uint32_t)p.total_segs, S, T);
+                     bucket_size, (uint32_t)p.total_segs, S, T);
   if (p.tree_wide_threads) {
     hipLaunchKernelGGL(reduce_tree_wide_kernel, dim3(p.K + 2, p.W, 1), dim3(p.tree_wide_threads),
                        p.tree_wide_threads * sizeof(PtI), st, (const PtI*)S, (const PtI*)T, p.nseg, p.K, partial);

@@ -28,7 +28,14 @@ digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   u256 k = load_u256(&scalars[t]);
-  if (scalars_mont) k = Fr::from_mont(k);
+  if (scalars_mont) {
+    k = Fr::from_mont(k);
+  } else {
+    // canonical layouts carry raw 256-bit integers (instance files, FFI callers): bring them below r first, so
+    // that every window size sees the same scalar (2^256 / r < 6: at most five subtractions)
+#pragma unroll 1
+    for (int i = 0; i < 5; ++i) k = Fr::reduce_once(k);
+  }
   const uint32_t half = 1u << (c - 1);
   uint32_t carry = 0;
   for (uint32_t w = 0; w < W; ++w) {

@@ -64,7 +64,6 @@ void launch_be32_to_le(hipStream_t st, const uint32_t* in, size_t words, uint32_
 void launch_ark_affine_to_affine(hipStream_t st, const uint8_t* in, uint32_t n, Affine* out);
 
 // k_accumulate.hip
-void launch_clear_buckets(hipStream_t st, const Plan& p, PtI* buckets);   // must precede launch_accumulate
 void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
                        PtI* partials, bool low_occupancy, hipEvent_t before_kernel, hipEvent_t after_kernel);
 
@@ -72,8 +71,10 @@ void launch_combine(hipStream_t st, const Plan& p, const SortBuffers& b, PtI* bu
 
 // k_reduce.hip
 int reduce_set_attributes(const char** failed);
-void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, PtI* S, PtI* T, PtI* tree_tmp,
-                   Jacobian* partial);
+// bucket_size: [W][nb] point counts (zero = the bucket was never written and counts as the identity), or nullptr
+// when every bucket holds a valid point (stage entry point sum_reduction)
+void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, const uint32_t* bucket_size, PtI* S, PtI* T,
+                   PtI* tree_tmp, Jacobian* partial);
 
 // k_misc.hip
 void launch_projective_to_affine(hipStream_t st, const Jacobian* in, uint32_t n, Affine* out);

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -115,6 +116,15 @@ int fail(msm_amd_ctx* ctx, int status, const std::string& msg) {
   return status;
 }
 
+// Wait for everything this ctx has enqueued (error paths and set-up steps that reuse workspace 0).
+void drain_streams(msm_amd_ctx* ctx) {
+  (void)hipStreamSynchronize(ctx->front_stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->reduce_stream);
+  (void)hipStreamSynchronize(ctx->reduce_stream2);
+  (void)hipGetLastError();
+}
+
 #define HIP_TRY(ctx, expr)                                                                        \
   do {                                                                                            \
     hipError_t _e = (expr);                                                                       \
@@ -203,12 +213,16 @@ Plan make_plan(size_t n_scalars, uint32_t c, uint32_t windows = 0) {
     p.fb = 10;
     p.hb = p.lb - 10;
   }
-  // accumulate work items: at most CH points each.  The accumulate kernel wants >= ~400 k items (two full
-  // rounds of 3 waves/SIMD on 1024 SIMDs) so that the chip stays full until the end; buckets longer than CH
-  // are cut into several items whose partial sums the combine kernels add up (one extra addition per cut).
+  // accumulate work items: at most CH points each; buckets longer than CH are cut into several items whose partial
+  // sums the combine kernels add up (one extra full addition per cut, and a second affine+affine start).  Uniform
+  // scalars must split (almost) nothing: CH >= mean + 5 sigma of the Poisson bucket size (2^20 points, c = 16: mean
+  // 32, CH = 64; the round-1 rule picked 32 there and cut 228 k of 524 k buckets in two).  Only when the buckets
+  // alone cannot fill the chip twice (2 waves/SIMD x 1024 SIMDs x 64 lanes = 131 k lanes per round) are items made
+  // shorter on purpose.  Skewed inputs (equal scalars, narrow top windows) still get cut at CH.
+  const double mean_len = (double)n / (double)p.nb;
   uint32_t ch = 16;
-  const size_t target_len = ((size_t)p.W * n) / 393216;
-  while (ch < 512 && (size_t)ch * 2 <= target_len) ch <<= 1;
+  while (ch < 512 && (double)ch < mean_len + 5.0 * std::sqrt(mean_len)) ch <<= 1;
+  while (ch > 16 && (size_t)p.W * p.nb + ((size_t)p.W * n) / ch < 262144) ch >>= 1;
   if (const char* e = std::getenv("MSM_AMD_CH")) {
     const int v = std::atoi(e);
     if (v >= 16 && v <= 512 && (v & (v - 1)) == 0) ch = (uint32_t)v;
@@ -410,13 +424,14 @@ size_t point_bytes(int layout) {
 }
 
 // Window reduction of a production-layout bucket matrix: buckets [W][nb] -> partial [W][K+1] on device.
-int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, hipStream_t st, const Plan& p, const PtI* buckets) {
+int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, hipStream_t st, const Plan& p, const PtI* buckets,
+                   const uint32_t* bucket_size) {
   int rc;
   if ((rc = ensure(ctx, w.S, p.total_segs * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.T, p.total_segs * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.tree_tmp, p.partial_count * p.tree_parts * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.partial, p.partial_count * sizeof(Jacobian)))) return rc;
-  launch_reduce(st, p, buckets, (PtI*)w.S.p, (PtI*)w.T.p, (PtI*)w.tree_tmp.p, (Jacobian*)w.partial.p);
+  launch_reduce(st, p, buckets, bucket_size, (PtI*)w.S.p, (PtI*)w.T.p, (PtI*)w.tree_tmp.p, (Jacobian*)w.partial.p);
   HIP_TRY(ctx, hipGetLastError());
   return MSM_AMD_OK;
 }
@@ -508,9 +523,9 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_DIGITS], fs));
   launch_sort(fs, p, sb);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_SORT], fs));
-  // the bucket matrix is cleared on the front stream too (its last reader, the reduction of the previous user of
-  // this workspace, was waited for above), so the main stream goes from one accumulate straight to the next
-  launch_clear_buckets(fs, p, (PtI*)w.buckets.p);
+  // the bucket matrix is NOT cleared: a bucket without points gets no work item and is never written; the window
+  // reduction reads bucket_size and takes such a slot as the identity (the reference relies on Metal's zero-filled
+  // fresh buffers instead, msm.rs:154-156)
   if (fs != st) {
     HIP_TRY(ctx, hipEventRecord(w.front_done, fs));
     HIP_TRY(ctx, hipStreamWaitEvent(st, w.front_done, 0));
@@ -532,7 +547,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   if (rs != st) HIP_TRY(ctx, hipStreamWaitEvent(rs, w.acc_done, 0));
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_RED_S], rs));
   launch_combine(rs, p, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p);
-  if ((rc = enqueue_reduce(ctx, w, rs, p, (const PtI*)w.buckets.p))) return rc;
+  if ((rc = enqueue_reduce(ctx, w, rs, p, (const PtI*)w.buckets.p, (const uint32_t*)w.bsize.p))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial, w.partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, rs));
   HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial + slot.h_partial_cap, w.counters.p, sizeof(PlanCounters),
@@ -609,12 +624,8 @@ int submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, s
     Workspace& w = ctx->ws[ctx->next_ws];
     ctx->next_ws = (ctx->next_ws + 1) % kWorkspaces;
     int rc = enqueue_msm(ctx, w, B.slots[i], scalar_layout, point_layout, d_scalars[i], d_points[i], n[i], &B.plans[i]);
-    if (rc) {
-      (void)hipStreamSynchronize(ctx->front_stream);
-      (void)hipStreamSynchronize(ctx->stream);
-      (void)hipStreamSynchronize(ctx->reduce_stream);
-  (void)hipStreamSynchronize(ctx->reduce_stream2);
-      (void)hipStreamSynchronize(ctx->reduce_stream2);
+    if (rc) {   // nothing of a failed submit stays in flight; the batch slot was never marked active
+      drain_streams(ctx);
       return rc;
     }
   }
@@ -631,7 +642,12 @@ int wait_batch(msm_amd_ctx* ctx, int ticket) {
   ctx->timings = msm_amd_timings{};
   for (size_t i = 0; i < B.n_inst; ++i) {
     InstanceSlot& s = B.slots[i];
-    HIP_TRY(ctx, hipEventSynchronize(s.ev[EV_REDUCE]));
+    const hipError_t e = hipEventSynchronize(s.ev[EV_REDUCE]);
+    if (e != hipSuccess) {   // release the ticket on every exit: a failed wait must not block later submits
+      drain_streams(ctx);
+      B.active = false;
+      return fail(ctx, MSM_AMD_PIPELINE_ERROR, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+    }
     const auto t0 = std::chrono::steady_clock::now();
     const Jacobian res = normalise(host_combine(s.h_partial, B.plans[i]));
     const float final_ms =
@@ -1337,6 +1353,7 @@ int msm_amd_bucket_wise_accumulation(msm_amd_ctx* ctx, const uint32_t* sorted_pa
     return fail(ctx, MSM_AMD_INPUT_ERROR, "bad bucket_wise_accumulation arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  drain_streams(ctx);   // workspace 0 may belong to an MSM between submit_batch_device and wait_batch
   hipStream_t st = ctx->stream;
   int rc;
   const size_t pts_bytes = n_points * 96, bkt_bytes = (size_t)total_buckets * 96;
@@ -1370,6 +1387,7 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   if (c > 24) return fail(ctx, MSM_AMD_INPUT_ERROR, "buckets_size too large");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  drain_streams(ctx);   // workspace 0 may belong to an MSM between submit_batch_device and wait_batch
   hipStream_t st = ctx->stream;
   const Plan p = make_reduce_plan(c, num_windows);
   int rc;
@@ -1381,7 +1399,7 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   const size_t words = (size_t)buckets_size * num_windows * 3;
   launch_be32_to_le(st, (const uint32_t*)ctx->scratch_a.p, words, (uint32_t*)ctx->scratch_b.p);
   launch_pad_buckets(st, (const Jacobian*)ctx->scratch_b.p, buckets_size, p.W, p.lb, (PtI*)ctx->ws[0].buckets.p);
-  if ((rc = enqueue_reduce(ctx, ctx->ws[0], st, p, (const PtI*)ctx->ws[0].buckets.p))) return rc;
+  if ((rc = enqueue_reduce(ctx, ctx->ws[0], st, p, (const PtI*)ctx->ws[0].buckets.p, nullptr))) return rc;
   std::vector<Jacobian> partial(p.partial_count);
   HIP_TRY(ctx, hipMemcpyAsync(partial.data(), ctx->ws[0].partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, st));

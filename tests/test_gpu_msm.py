@@ -303,3 +303,24 @@ def test_known_answers_without_the_oracle(cfg, msm_pkg):
     assert o.decode_jacobian_mont_le(msm_pkg.gpu_msm_h2c(sb, pb, cfg)) is None
     sb, pb = h2c_instance_bytes([G] * 3, [1, 1, 1])                                  # three equal points: 3G
     assert o.decode_jacobian_mont_le(msm_pkg.gpu_msm_h2c(sb, pb, cfg)) == g3
+
+
+@pytest.mark.parametrize("c", [0, 5, 15, 16, 17])
+def test_canonical_scalars_at_or_above_r_are_reduced(cfg, msm_pkg, c):
+    """Raw 256-bit integers in the canonical layouts (instance files, FFI callers) may exceed r; the result must be
+    that of the scalar mod r for every window size (bit 255 used to be dropped at c = 15 / 17)."""
+    pts, sc = small_instance(21, 40)
+    raw = list(sc)
+    raw[0] = o.R_ORDER + 5
+    raw[1] = (1 << 256) - 1
+    raw[2] = o.R_ORDER
+    raw[3] = (1 << 255) + 12345
+    raw[4] = 5 * o.R_ORDER + 1
+    pb = b"".join(o.encode_affine_h2c(p) for p in pts)
+    sb = b"".join(k.to_bytes(32, "little") for k in raw)
+    cfg.set_window_size(c)
+    try:
+        out = cfg.msm(sb, pb, len(pts), scalar_layout=msm_pkg.SCALAR_CANON_LE)
+    finally:
+        cfg.set_window_size(0)
+    assert o.decode_jacobian_mont_le(out) == o.msm_naive([k % o.R_ORDER for k in raw], pts)
