@@ -8,8 +8,9 @@
  * Conventions
  *   - plain pointers and sizes only; no C++ or torch types;
  *   - every function returns an int status (0 = OK), never aborts;
- *   - a ctx owns one HIP device + one stream + a grow-on-demand device workspace; calls on one ctx
- *     are serialised internally, different ctxs (one per GPU) run concurrently;
+ *   - a ctx owns one HIP device, four HIP streams (front end, accumulate, two reduce streams: consecutive
+ *     instances overlap their phases) and grow-on-demand device workspaces; calls on one ctx are serialised
+ *     internally, different ctxs (one per GPU) run concurrently;
  *   - all 256-bit values are little-endian (least significant byte first) unless a *_BE32 layout
  *     is named; field coordinates are in Montgomery form with R = 2^256 exactly as halo2curves and
  *     arkworks hold them in memory.
@@ -70,13 +71,16 @@ typedef struct msm_amd_timings {
   float accumulate_ms;  /* bucket_wise_accumulation (dominant kernel) */
   float reduce_ms;      /* sum_reduction: segment + tree kernels */
   float final_ms;       /* final_accumulation on the host (wall clock) */
-  float total_gpu_ms;   /* first kernel start -> last kernel end */
+  float total_gpu_ms;   /* SUM of the stage spans above (stages of neighbouring instances overlap on other streams,
+                           so this is not a wall interval) */
   uint32_t n;
   uint32_t window_size;
   uint32_t num_windows;
   uint32_t reserved;            /* number of instances the averages were taken over */
   float accumulate_kernel_ms;   /* accumulate_kernel alone (events directly around its launch) */
-  float reserved2[3];           /* [0] = work items of the last instance's accumulate grid (exact below 2^24) */
+  float reserved2[3];           /* [0] = work items of the last instance's accumulate grid (exact below 2^24)
+                                   [1] = 1 if bucket accumulation had not finished yet when the after_sort
+                                         callback of msm_amd_gpu_msm_h2c_sync fired, 0 if it had, -1 if no callback ran */
 } msm_amd_timings;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -94,8 +98,9 @@ const char* msm_amd_last_error(const msm_amd_ctx* ctx);
 
 /* encode_instances' `window_size: Option<u32>` (msm.rs:130-141): 0 = automatic, else 3..17. */
 int msm_amd_set_window_size(msm_amd_ctx* ctx, uint32_t window_size);
-/* The automatic choice for n points (reference policy: 3 if n < 32 else 15, msm.rs:135-141;
- * this library: 3 if n < 32 else clamp(floor(log2 n) - 5, 4, 15), equal at n >= 2^20). */
+/* The automatic choice for n points.  Reference policy: 3 if n < 32 else 15 (msm.rs:135-141).  This library: 3 below
+ * 32 points, then the window measured fastest on MI355X per size class (5 up to 2^14 points, 13 up to 2^16, 15 up
+ * to 2^19, 16 up to 2^21, 17 beyond); this function is the only source of truth -- results never depend on it. */
 uint32_t msm_amd_auto_window_size(size_t n);
 
 /* ---- whole-MSM entry points: host buffers ---------------------------------------------------- */
@@ -104,6 +109,14 @@ uint32_t msm_amd_auto_window_size(size_t n);
  * out: 96 B Jacobian (x, y, z) Montgomery LE, normalised to z = R mod p, or z = 0 for the identity:
  * memcpy-compatible with bn256::G1 / G1Projective. */
 int msm_amd_gpu_msm_h2c(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n, void* out96);
+/* gpu_msm_h2c_sync(scalars, points, sync_pair: Arc<(Mutex<bool>, Condvar)>) (msm.rs:237-349): the same MSM, and
+ * `after_sort(user)` is called once, on the calling thread, as soon as the sort stage of this MSM has finished on
+ * the GPU -- the point where the reference sets the flag and notifies the condvar (msm.rs:306-312) so that a
+ * hybrid caller may start its CPU half (gpu_with_cpu, msm.rs:403-415).  after_sort may be NULL.  The callback must
+ * not call into the same ctx. */
+typedef void (*msm_amd_after_sort_fn)(void* user);
+int msm_amd_gpu_msm_h2c_sync(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n,
+                             msm_amd_after_sort_fn after_sort, void* user, void* out96);
 /* metal_msm::<ArkG, ArkFr>(points, scalars, &mut config) -> Result<ArkG, MetalError> (msm.rs:220-234).
  * points: n x 96 B MSM_AMD_POINT_ARK_PROJECTIVE; scalars: n x 32 B MSM_AMD_SCALAR_MONT_LE. */
 int msm_amd_metal_msm_ark(msm_amd_ctx* ctx, const void* points, const void* scalars, size_t n, void* out96);
@@ -118,9 +131,14 @@ int msm_amd_msm_batch(msm_amd_ctx* ctx, int scalar_layout, int point_layout, siz
 /* ---- hybrid front-end ----------------------------------------------------------------------- */
 /* msm_best::<G1Affine, ..>(scalars, points) -> G1 (msm.rs:424-445): filter_zeros (drop zero scalars when at
  * least 30 % of them are zero, msm.rs:448-507, done here by a device compaction) and then the MSM.  The
- * reference sends n < 2^17 to halo2curves on the CPU because its Metal path is slower there; this library
- * stays on the GPU for every n (no CPU fallback is linked behind this entry point).  h2c layouts. */
+ * reference sends n < 2^17 to halo2curves on the CPU because its Metal path is slower there (msm.rs:440-444);
+ * the same dispatch exists here with the threshold measured on MI355X: below msm_amd_cpu_dispatch_below()
+ * points one blocking GPU call costs more than the product's host bucket method (host_msm, the CPU half of
+ * gpu_with_cpu), so those sizes are computed on the host -- an explicit size dispatch as in the reference,
+ * never a fallback: without a GPU this entry point fails like every other.  h2c layouts. */
 int msm_amd_msm_best(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n, void* out96);
+/* msm_best's size threshold (the reference's is 2^17, msm.rs:440): sizes below it go to the host bucket method. */
+size_t msm_amd_cpu_dispatch_below(void);
 /* gpu_with_cpu (msm.rs:366-421): the first split_at points go to the GPU, the rest to a multi-threaded host
  * bucket method (cpu_threads <= 0: all hardware threads); the two results are added.  h2c layouts. */
 int msm_amd_gpu_with_cpu(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n, size_t split_at,

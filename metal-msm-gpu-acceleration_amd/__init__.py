@@ -33,6 +33,7 @@ def op_is_point(op):
 EXPORTS = [
     "msm_amd_init", "msm_amd_init_reusable", "msm_amd_get_global", "msm_amd_destroy", "msm_amd_strerror",
     "msm_amd_last_error", "msm_amd_set_window_size", "msm_amd_auto_window_size", "msm_amd_gpu_msm_h2c",
+    "msm_amd_gpu_msm_h2c_sync", "msm_amd_cpu_dispatch_below",
     "msm_amd_metal_msm_ark", "msm_amd_msm", "msm_amd_msm_batch", "msm_amd_msm_best", "msm_amd_gpu_with_cpu",
     "msm_amd_reference_split", "msm_amd_msm_device",
     "msm_amd_msm_batch_device", "msm_amd_submit_batch_device", "msm_amd_wait_batch", "msm_amd_device_alloc", "msm_amd_device_free", "msm_amd_copy_to_device",
@@ -47,6 +48,9 @@ EXPORTS = [
     "msm_amd_msm_prepared", "msm_amd_sum_points", "msm_amd_tables_build", "msm_amd_tables_build_device",
     "msm_amd_tables_info", "msm_amd_tables_free", "msm_amd_msm_tables",
 ]
+
+
+AFTER_SORT_FN = ctypes.CFUNCTYPE(None, c_void_p)   # msm_amd_after_sort_fn
 
 
 class Timings(ctypes.Structure):
@@ -113,6 +117,9 @@ def _lib():
         L.msm_amd_auto_window_size.restype = c_uint32
         L.msm_amd_gpu_msm_h2c.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
         L.msm_amd_metal_msm_ark.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.msm_amd_gpu_msm_h2c_sync.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, AFTER_SORT_FN, c_void_p, c_void_p]
+        L.msm_amd_cpu_dispatch_below.argtypes = []
+        L.msm_amd_cpu_dispatch_below.restype = c_size_t
         L.msm_amd_msm.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
         L.msm_amd_msm_batch.argtypes = [c_void_p, c_int, c_int, c_size_t, POINTER(c_void_p), POINTER(c_void_p),
                                         POINTER(c_size_t), c_void_p]
@@ -415,6 +422,17 @@ def gpu_msm_h2c(scalars: bytes, points: bytes, config: MsmConfig | None = None) 
     cfg = config or setup_metal_state_reusable()
     out = ctypes.create_string_buffer(96)
     cfg._check(_lib().msm_amd_gpu_msm_h2c(cfg.h, scalars, points, n, out))
+    return out.raw
+
+
+def gpu_msm_h2c_sync(scalars: bytes, points: bytes, after_sort, config: MsmConfig | None = None) -> bytes:
+    """gpu_msm_h2c_sync (msm.rs:237-349): `after_sort()` is called once the GPU has finished sorting this MSM's
+    bucket indices -- where the reference notifies its (Mutex<bool>, Condvar) pair (msm.rs:306-312)."""
+    n = min(len(scalars) // 32, len(points) // 64)
+    cfg = config or setup_metal_state_reusable()
+    out = ctypes.create_string_buffer(96)
+    cb = AFTER_SORT_FN((lambda _user: after_sort()) if after_sort is not None else 0)
+    cfg._check(_lib().msm_amd_gpu_msm_h2c_sync(cfg.h, scalars, points, n, cb, None, out))
     return out.raw
 
 

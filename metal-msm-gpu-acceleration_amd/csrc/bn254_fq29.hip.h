@@ -32,6 +32,28 @@ struct fe29 {
   uint32_t l[9];
 };
 
+// Pins a limb as an opaque 32-bit VGPR value (no instruction is emitted).  LLVM hoists the zero-extension of a
+// limb towards its definition; when definition and multiplication end up in different basic blocks (every
+// multiplication after the exceptional-case branch of an addition, every loop-carried accumulator limb) the
+// instruction selector no longer knows that the upper half of the 64-bit operand is zero and multiplies
+// 64 x 32 bits: two v_mad_u64_u32 and two v_mov per limb product instead of one.  Measured in the accumulate
+// kernel's ISA before this pin: 1243 instead of 1143 multiplier instructions and 200 moves per mixed addition.
+MSM_HD uint32_t limb32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MSM_FQ29_NOPIN)   // NOPIN: A/B builds of tools/microbench only
+  asm("" : "+v"(x));
+#endif
+  return x;
+}
+MSM_HD fe29 pin_limbs(const fe29& a) {
+  fe29 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  _Pragma("unroll") for (int i = 0; i < 9; ++i) r.l[i] = limb32(a.l[i]);
+#else
+  r = a;
+#endif
+  return r;
+}
+
 enum KSel { K4E30 = 0, K8E30 = 1, K8E31 = 2, K16E30 = 3, K16E31 = 4 };
 
 struct Fq29 {
@@ -130,8 +152,68 @@ struct Fq29 {
     return r;
   }
 
+
+  // ---- product-scanning ("FIPS") forms: one running 64-bit accumulator per column, whose chain STARTS from the
+  // carry of the column below (the free 64-bit addend of the first v_mad_u64_u32), so no 64-bit additions are
+  // needed to propagate carries, and no 17 column sums are live at once.  Same values as mul / sqr / mul2.  The
+  // multiply-adds are written as inline assembly because LLVM re-associates a chain of 64-bit additions back
+  // into independent partial sums plus 64-bit adds.
+  MSM_HD static void mad64(uint64_t& t, uint32_t x, uint32_t y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t co;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(t), "=s"(co) : "v"(x), "v"(y));
+#else
+    t += (uint64_t)x * y;
+#endif
+  }
+  MSM_HD static void mad64c(uint64_t& t, uint32_t x, uint32_t c) {   // c: a constant limb of p (scalar register)
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t co;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(t), "=s"(co) : "v"(x), "s"(c));
+#else
+    t += (uint64_t)x * c;
+#endif
+  }
+  // SQUARE: one product, x = 2a (doubled limbs), y = a: cross products i < j only, plus a_(k/2)^2 in even columns
+  template <int NPROD, bool SQUARE = false>
+  MSM_HD static fe29 fips(const fe29* const (&x)[NPROD], const fe29* const (&y)[NPROD]) {
+    uint32_t m[9];
+    fe29 r;
+    uint64_t t = 0;
+    MSM_UNROLL for (int k = 0; k < 17; ++k) {
+      MSM_UNROLL for (int q = 0; q < NPROD; ++q) {
+        MSM_UNROLL for (int i = 0; i < 9; ++i) {
+          const int j = k - i;
+          if (j >= 0 && j < 9 && (!SQUARE || i < j)) mad64(t, x[q]->l[i], y[q]->l[j]);
+        }
+        if (SQUARE && (k & 1) == 0) mad64(t, y[q]->l[k >> 1], y[q]->l[k >> 1]);
+      }
+      MSM_UNROLL for (int i = 0; i < 9; ++i) {
+        const int j = k - i;
+        if (i < k && j >= 1 && j < 9) mad64c(t, m[i], p(j));
+      }
+      if (k < 9) {
+        m[k] = ((uint32_t)t * INV) & MASK;
+        mad64c(t, m[k], p(0));
+      } else {
+        r.l[k - 9] = (uint32_t)t & MASK;
+      }
+      t >>= 29;
+    }
+    r.l[8] = (uint32_t)t;
+    return r;
+  }
+
   // a*b*rho^-1 mod p (lazily reduced).  81 + 81 limb products, no carry instructions.
-  MSM_HD static fe29 mul(const fe29& a, const fe29& b) {
+  MSM_HD static fe29 mul(const fe29& a_in, const fe29& b_in) {
+    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in);
+#if defined(MSM_FQ29_FIPS)
+    {
+      const fe29* const xs[1] = {&a};
+      const fe29* const ys[1] = {&b};
+      return fips<1>(xs, ys);
+    }
+#endif
     uint64_t A[17];
     MSM_UNROLL for (int k = 0; k < 17; ++k) {
       uint64_t s = 0;
@@ -147,7 +229,15 @@ struct Fq29 {
   // (a*b + c*d)*rho^-1 with ONE Montgomery reduction: 81 + 81 + 81 limb products instead of 2 x (81 + 81).
   // All four operands must be normalised (limbs <= 2^29 + 8) so that a column of 18 + 9 products stays
   // below 2^64.  Used for Y3 = R*T - Y1*PPP with d = -PPP.
-  MSM_HD static fe29 mul2(const fe29& a, const fe29& b, const fe29& c, const fe29& d) {
+  MSM_HD static fe29 mul2(const fe29& a_in, const fe29& b_in, const fe29& c_in, const fe29& d_in) {
+    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in), c = pin_limbs(c_in), d = pin_limbs(d_in);
+#if defined(MSM_FQ29_FIPS)
+    {
+      const fe29* const xs[2] = {&a, &c};
+      const fe29* const ys[2] = {&b, &d};
+      return fips<2>(xs, ys);
+    }
+#endif
     uint64_t A[17];
     MSM_UNROLL for (int k = 0; k < 17; ++k) {
       uint64_t s = 0;
@@ -164,7 +254,17 @@ struct Fq29 {
   }
 
   // a*a*rho^-1: 45 + 81 limb products (cross products use the doubled operand).
-  MSM_HD static fe29 sqr(const fe29& a) {
+  MSM_HD static fe29 sqr(const fe29& a_in) {
+    const fe29 a = pin_limbs(a_in);
+#if defined(MSM_FQ29_FIPS)
+    {
+      fe29 d2;
+      MSM_UNROLL for (int i = 0; i < 9; ++i) d2.l[i] = a.l[i] << 1;
+      const fe29* const xs[1] = {&d2};
+      const fe29* const ys[1] = {&a};
+      return fips<1, true>(xs, ys);
+    }
+#endif
     uint32_t d[9];
     MSM_UNROLL for (int i = 0; i < 9; ++i) d[i] = a.l[i] << 1;   // operand limbs <= 2^30 + 2^8 -> < 2^32
     uint64_t A[17];

@@ -2,10 +2,11 @@
 //
 // Replaces the reference's L2-L4 layers for the MSM path: MetalState (src/metal/abstraction/state.rs),
 // MetalMsmConfig/Instance + encode_instances + exec_metal_commands + gpu_msm_h2c_sync
-// (src/metal/msm.rs:28-349) and the stage drivers (src/metal/msm/*.rs).  All stages of one MSM are
-// enqueued on ONE HIP stream with no host synchronisation in between (the reference blocks after every
-// stage: prepare_buckets_indices.rs:35-36, bucket_wise_accumulation.rs:104-105, sum_reduction.rs:80-81);
-// the only device->host hand-off is the (c-2)*W partial window points for the host Horner pass.
+// (src/metal/msm.rs:28-349) and the stage drivers (src/metal/msm/*.rs).  The stages of one MSM are enqueued on
+// FOUR HIP streams (front end / accumulate / two alternating reduce streams, ordered by events) with no host
+// synchronisation in between (the reference blocks after every stage: prepare_buckets_indices.rs:35-36,
+// bucket_wise_accumulation.rs:104-105, sum_reduction.rs:80-81); the only device->host hand-off is the
+// (c-2)*W partial window points for the host Horner pass.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -30,6 +31,7 @@ namespace {
 
 constexpr uint32_t kModulusBits = 254;   // limbs_conversion.rs:172, :344
 constexpr uint32_t kMinWindow = 3, kMaxWindow = 17;   // u16 digits up to 15, u32 digits for 16 and 17
+constexpr size_t kCpuDispatchBelow = 5;               // msm_best: see cpu_dispatch_below()
 
 struct DeviceBuf {
   void* p = nullptr;
@@ -47,9 +49,9 @@ struct InstanceSlot {
 
 }  // namespace
 
-// Device buffers of one in-flight MSM.  A ctx owns two of them and alternates: the window reduction of
-// instance i runs on a side stream while the main stream already sorts (and then accumulates) instance i+1 in
-// the other workspace.  The reduction is latency-bound (about 25 dependent point additions on a few hundred
+// Device buffers of one in-flight MSM.  A ctx owns kWorkspaces (4) of them and uses them round-robin: the window
+// reduction of instance i runs on a side stream while the main stream accumulates instance i+1 and the front
+// stream already sorts instance i+2, each in its own workspace.  The reduction is latency-bound (about 25 dependent point additions on a few hundred
 // workgroups) and so is the sort front-end; running them side by side hides the shorter of the two.  (Running
 // whole instances on parallel streams was tried and gained little: a resident accumulate grid keeps the
 // 1024-thread sort workgroups of the other stream from being placed at all.)
@@ -104,6 +106,7 @@ struct msm_amd_ctx {
   DeviceBuf scratch_a, scratch_b, scratch_c, scratch_b2, scratch_c2;
   Batch batches[kMaxBatches];
   msm_amd_timings timings{};
+  float after_sort_state = -1.0f;   // timings.reserved2[1] of the next wait (see msm_amd_gpu_msm_h2c_sync)
 };
 
 namespace {
@@ -591,6 +594,7 @@ void accumulate_timings(msm_amd_ctx* ctx, InstanceSlot& s, const Plan& p, float 
   PlanCounters pc;
   std::memcpy(&pc, s.h_partial + s.h_partial_cap, sizeof pc);
   T.reserved2[0] = (float)pc.total_items;   // work items (= lanes with work) of the last instance's accumulate grid
+  T.reserved2[1] = ctx->after_sort_state;
 }
 
 // Batch of MSMs with device-resident inputs, in two halves so that callers can pipeline batches:
@@ -903,6 +907,42 @@ int msm_amd_gpu_msm_h2c(msm_amd_ctx* ctx, const void* scalars, const void* point
   return msm_amd_msm(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, scalars, points, n, out96);
 }
 
+int msm_amd_gpu_msm_h2c_sync(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n,
+                             msm_amd_after_sort_fn after_sort, void* user, void* out96) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  if (!scalars || !points || !out96 || n == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "n == 0 or null pointer");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->scratch_b, n * 32))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch_c, n * 64))) return rc;
+  hipStream_t up = ctx->overlap_front ? ctx->front_stream : ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars, n * 32, hipMemcpyHostToDevice, up));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, points, n * 64, hipMemcpyHostToDevice, up));
+  const void* ds = ctx->scratch_b.p;
+  const void* dp = ctx->scratch_c.p;
+  int ticket = -1;
+  if ((rc = submit_batch_device(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, 1, &ds, &dp, &n, out96, &ticket)))
+    return rc;
+  ctx->after_sort_state = -1.0f;
+  if (after_sort) {
+    InstanceSlot& s = ctx->batches[ticket].slots[0];
+    const hipError_t e = hipEventSynchronize(s.ev[EV_SORT]);   // sorted indices of this MSM exist (msm.rs:306-312)
+    if (e != hipSuccess) {
+      drain_streams(ctx);
+      ctx->batches[ticket].active = false;
+      return fail(ctx, MSM_AMD_PIPELINE_ERROR, std::string("hipEventSynchronize(sort): ") + hipGetErrorString(e));
+    }
+    const hipError_t q = hipEventQuery(s.ev[EV_ACC]);
+    ctx->after_sort_state = q == hipErrorNotReady ? 1.0f : 0.0f;
+    (void)hipGetLastError();
+    after_sort(user);
+  }
+  rc = wait_batch(ctx, ticket);
+  ctx->after_sort_state = -1.0f;
+  return rc;
+}
+
 int msm_amd_metal_msm_ark(msm_amd_ctx* ctx, const void* points, const void* scalars, size_t n, void* out96) {
   return msm_amd_msm(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_ARK_PROJECTIVE, scalars, points, n, out96);
 }
@@ -942,9 +982,27 @@ int msm_amd_gpu_with_cpu(msm_amd_ctx* ctx, const void* scalars, const void* poin
   return MSM_AMD_OK;
 }
 
+// msm_best's size dispatch (msm.rs:440-444: `if n < 2^17 { cpu } else { gpu }`), threshold measured on MI355X with
+// tools/crossover.py (profiles/r02_crossover.txt): one blocking GPU call costs ~0.35 ms of launches, event waits and
+// host Horner whatever n is; the single-threaded host bucket method is faster than that only for a handful of points.
+static size_t cpu_dispatch_below() {
+  static const size_t v = [] {
+    if (const char* e = std::getenv("MSM_AMD_CPU_BELOW")) return (size_t)std::strtoull(e, nullptr, 10);
+    return (size_t)kCpuDispatchBelow;
+  }();
+  return v;
+}
+
+size_t msm_amd_cpu_dispatch_below(void) { return cpu_dispatch_below(); }
+
 int msm_amd_msm_best(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n, void* out96) {
   if (!ctx || !scalars || !points || !out96 || n == 0 || n > 0x7FFFFFFFull)
     return fail(ctx, MSM_AMD_INPUT_ERROR, "bad msm_best arguments");
+  if (n < cpu_dispatch_below()) {   // explicit size dispatch as in the reference, on a ctx that owns a GPU
+    const Jacobian r = normalise(host_msm((const u256*)scalars, 1, (const Affine*)points, n, 1));
+    std::memcpy(out96, &r, 96);
+    return MSM_AMD_OK;
+  }
   std::unique_lock<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -983,8 +1041,6 @@ int msm_amd_msm_best(msm_amd_ctx* ctx, const void* scalars, const void* points, 
     std::memcpy(out96, &id, 96);
     return MSM_AMD_OK;
   }
-  // The reference sends n < 2^17 to the CPU because its Metal path loses there (msm.rs:440-444); on MI355X the
-  // GPU path wins for every n that is worth a call, and no CPU MSM fallback is linked behind this entry point.
   return run_batch_device(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, 1, &ds, &dp, &m, out96);
 }
 

@@ -10,7 +10,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmsm_oracle.so")
 _LIB = None
 # what oracle_msm_best does (printed in bench.py's cpu_baseline)
-MSM_BEST_ALGORITHM = "chunk-parallel Pippenger, serial Jacobian buckets, signed digits"
+MSM_BEST_ALGORITHM = ("window-parallel Pippenger (halo2curves 0.7 msm_best shape): c = ceil(ln n), Booth digits, "
+                      "affine buckets with batched additions (64 per shared inversion), Jacobian side buckets for "
+                      "collisions, summation by parts; points additionally split into groups so that all threads have "
+                      "a window task")
 
 
 def build(force=False):
@@ -28,8 +31,9 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.oracle_gen_instance.argtypes = [c_uint64, c_size_t, c_int, c_void_p, c_void_p, c_int]
         L.oracle_gen_instance.restype = None
-        for name in ("oracle_msm_best",):
+        for name in ("oracle_msm_best", "oracle_msm_chunked"):
             getattr(L, name).argtypes = [c_char_p, c_char_p, c_size_t, c_int, c_void_p]
+        L.oracle_msm_best_ex.argtypes = [c_char_p, c_char_p, c_size_t, c_int, c_int, c_void_p, c_void_p]
         L.oracle_msm_reference_pipeline.argtypes = [c_char_p, c_char_p, c_size_t, c_uint32, c_void_p]
         L.oracle_msm_naive.argtypes = [c_char_p, c_char_p, c_size_t, c_void_p]
         L.oracle_dlog_instance.argtypes = [c_char_p, c_char_p, c_char_p, c_size_t, c_int, c_void_p, c_void_p]
@@ -45,7 +49,25 @@ def lib():
 
 
 def default_threads():
-    return max(1, len(os.sched_getaffinity(0)))
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a container that sees
+    256 logical CPUs but owns 16 of them must not start 256 compute threads)."""
+    n = max(1, len(os.sched_getaffinity(0)))
+    quota = None
+    try:                                    # cgroup v2
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:                                # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
 
 
 def gen_instance(seed, n, scalars_mont=True, threads=None):
@@ -59,6 +81,24 @@ def gen_instance(seed, n, scalars_mont=True, threads=None):
 def msm_best(scalars: bytes, points: bytes, n: int, threads=None) -> bytes:
     out = ctypes.create_string_buffer(96)
     rc = lib().oracle_msm_best(scalars, points, n, threads or default_threads(), out)
+    assert rc == 0
+    return out.raw
+
+
+def msm_best_ex(scalars: bytes, points: bytes, n: int, threads=None, groups=0):
+    """(result, info) with info = {window, windows, groups, threads_used}; groups = 1 is the halo2curves shape
+    exactly (one task per window), 0 = as many point groups as keep all threads busy."""
+    out = ctypes.create_string_buffer(96)
+    info = (c_uint32 * 4)()
+    rc = lib().oracle_msm_best_ex(scalars, points, n, threads or default_threads(), groups, out, info)
+    assert rc == 0
+    return out.raw, {"window": info[0], "windows": info[1], "groups": info[2], "threads_used": info[3]}
+
+
+def msm_chunked(scalars: bytes, points: bytes, n: int, threads=None) -> bytes:
+    """Round-1 baseline (points split over threads, serial Jacobian bucket method per slice): a second checker."""
+    out = ctypes.create_string_buffer(96)
+    rc = lib().oracle_msm_chunked(scalars, points, n, threads or default_threads(), out)
     assert rc == 0
     return out.raw
 

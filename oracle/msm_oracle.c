@@ -12,11 +12,12 @@
  *   - the CPU MSM the reference is compared with and hybridised with, halo2curves 0.7.0
  *     `msm::msm_best` (Cargo.toml:48; called at msm.rs:412,443,600 and gpu_profiler.rs:158).  That crate
  *     is NOT vendored and cannot be built here (no cargo/rustc).  oracle_msm_best restates its
- *     published algorithm from memory of the 0.7 line (unverified offline): split the points over
- *     the worker threads, each thread runs a serial bucket method with window c = ceil(ln n) (3 below
- *     32 points), signed Booth digits and Jacobian+affine bucket additions, running-sum bucket
- *     reduction, Horner over windows; the per-thread results are added.  It is the timed CPU baseline
- *     ("port"), labelled as a restatement, never as halo2curves itself.
+ *     published algorithm from memory of the 0.7 line (unverified offline): window c = ceil(ln n)
+ *     (3 below 32 points), one task per window, Booth digits, affine buckets updated in batches of 64
+ *     with one shared inversion, Jacobian side buckets for colliding updates, summation by parts,
+ *     window values shifted and added (see oracle_msm_best_ex).  It is the timed CPU baseline
+ *     ("port"), labelled as a restatement, never as halo2curves itself.  oracle_msm_chunked (points
+ *     split over threads, serial Jacobian bucket method per slice) is kept as a second checker.
  *
  * PARITY PINNING: see oracle/bn254_ref.py -- the reference holds no golden vectors for this path, so
  * at the literal-fixture level this oracle is "parity unpinned"; it is pinned mathematically (unique
@@ -325,8 +326,9 @@ static void* dm_worker(void* arg) {
   return NULL;
 }
 
-/* Restatement of halo2curves::msm::msm_best (see header): thread-parallel over point slices. */
-int oracle_msm_best(const uint8_t* scalars32_mont, const uint8_t* points64, size_t n, int threads, uint8_t* out96) {
+/* The round-1 baseline, kept as a second, independent checker: the points are split over the threads and every
+ * thread runs the serial bucket method above on its slice (the shape of halo2curves' older best_multiexp). */
+int oracle_msm_chunked(const uint8_t* scalars32_mont, const uint8_t* points64, size_t n, int threads, uint8_t* out96) {
   if (n == 0) return 1;
   if (threads < 1) threads = 1;
   if ((size_t)threads > n) threads = (int)n;
@@ -351,6 +353,210 @@ int oracle_msm_best(const uint8_t* scalars32_mont, const uint8_t* points64, size
   memcpy(out96, &total, 96);
   free(jobs); free(dj); free(th); free(ks);
   return 0;
+}
+
+
+/* ------------------------------------------------------------------------------------------------
+ * halo2curves 0.7 `msm::msm_best`, restated from memory of its published source (the crate is not in the
+ * container; see the header): one rayon task per WINDOW; Booth-recoded digits; buckets are kept AFFINE and up
+ * to 64 pending (bucket += +/-base) updates are executed together with one shared field inversion (batch_add:
+ * prefix products of the denominators, one inversion, back-substitution -- 6 multiplications per addition); an
+ * update whose bucket already has a pending entry in the schedule goes to a Jacobian side bucket instead
+ * ("greedy accumulation"); window value by summation by parts over (Jacobian side bucket + affine bucket);
+ * the window is shifted into place by c*w doublings; window values are added.  Beyond halo2curves (which can
+ * keep only `windows` = 19 cores busy at 2^20 points), `groups` > 1 splits the points into groups that run the
+ * same window tasks side by side, so that every core of the node has work; the per-group results are added.
+ * Identity bases (0,0) are skipped (halo2curves assumes there are none). */
+#define SCHED_BATCH 64
+
+/* modular inverse of a Montgomery residue, result a Montgomery residue: binary extended Euclid on the integer
+ * (a R)^-1 = a^-1 R^-1, then two Montgomery products by R^2 bring it to a^-1 R. */
+static inline void fe_shr1(fe* a, uint64_t top) {
+  a->v[0] = (a->v[0] >> 1) | (a->v[1] << 63); a->v[1] = (a->v[1] >> 1) | (a->v[2] << 63);
+  a->v[2] = (a->v[2] >> 1) | (a->v[3] << 63); a->v[3] = (a->v[3] >> 1) | (top << 63);
+}
+static inline void halve_mod(const field_t* F, fe* x) {   /* x/2 mod p for x < p */
+  if (x->v[0] & 1) { uint64_t c = raw_add(x, x, &F->mod); fe_shr1(x, c); } else fe_shr1(x, 0);
+}
+static void f_inv_fast(const field_t* F, fe* r, const fe* a) {
+  fe u = *a, v = F->mod, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
+  const fe one = {{1, 0, 0, 0}};
+  if (fe_is_zero(a)) { *r = *a; return; }
+  while (!fe_eq(&u, &one) && !fe_eq(&v, &one)) {
+    while (!(u.v[0] & 1)) { fe_shr1(&u, 0); halve_mod(F, &x1); }
+    while (!(v.v[0] & 1)) { fe_shr1(&v, 0); halve_mod(F, &x2); }
+    if (fe_geq(&u, &v)) { raw_sub(&u, &u, &v); f_sub(F, &x1, &x1, &x2); }
+    else { raw_sub(&v, &v, &u); f_sub(F, &x2, &x2, &x1); }
+  }
+  fe t = fe_eq(&u, &one) ? x1 : x2;
+  f_mul(F, &t, &t, &F->r2);      /* a^-1 R^-1 * R^2 * R^-1 = a^-1        */
+  f_mul(F, r, &t, &F->r2);       /* a^-1 * R^2 * R^-1     = a^-1 R      */
+}
+
+static inline int32_t booth_digit(const fe* k, uint32_t w, uint32_t c) {
+  const uint32_t start = w * c;
+  uint32_t raw;
+  if (start == 0) raw = get_bits(k, 0, c) << 1; else raw = get_bits(k, start - 1, c + 1);
+  const uint32_t sign = (raw >> c) & 1;
+  int32_t d = (int32_t)((raw + 1) >> 1);
+  if (sign) d = d - (int32_t)(1u << c);
+  return d;                                         /* in [-2^(c-1), 2^(c-1)] */
+}
+
+typedef struct { uint32_t base, buck; int neg; } sched_pt;
+typedef struct {
+  aff_t* a_bucks;          /* affine buckets, (0,0) = empty */
+  jac_t* j_bucks;          /* Jacobian side buckets for updates that collide with a pending one */
+  uint8_t* pending;        /* bucket has an entry in the current batch */
+  sched_pt set[SCHED_BATCH];
+  int ptr;
+} schedule_t;
+
+/* executes the pending updates bucket[b] += +/- base with ONE inversion */
+static void sched_execute(schedule_t* S, const aff_t* bases) {
+  fe t[SCHED_BATCH], z[SCHED_BATCH];
+  uint8_t kind[SCHED_BATCH];                        /* 0 = plain store / nothing, 1 = add, 2 = double */
+  fe acc = FQ.one;
+  const int size = S->ptr;
+  for (int i = 0; i < size; ++i) {
+    const sched_pt sp = S->set[i];
+    aff_t* b = &S->a_bucks[sp.buck];
+    const aff_t* q = &bases[sp.base];
+    kind[i] = 0;
+    if (aff_is_id(b)) continue;                     /* empty bucket: set it in the second pass */
+    fe qy = q->y; if (sp.neg) f_neg(&FQ, &qy, &q->y);
+    if (fe_eq(&b->x, &q->x)) {
+      if (fe_eq(&b->y, &qy)) {                      /* doubling: lambda = 3 x^2 / 2 y */
+        fe xx, n3; QSQR(&xx, &q->x); QADD(&n3, &xx, &xx); QADD(&n3, &n3, &xx);
+        QADD(&z[i], &qy, &qy); QMUL(&t[i], &acc, &n3); QMUL(&acc, &acc, &z[i]); kind[i] = 2;
+      } else { memset(b, 0, sizeof *b); kind[i] = 3; }   /* P + (-P): bucket becomes empty, skip in pass 2 */
+      continue;
+    }
+    fe dy; QSUB(&z[i], &q->x, &b->x); QSUB(&dy, &qy, &b->y);
+    QMUL(&t[i], &acc, &dy); QMUL(&acc, &acc, &z[i]); kind[i] = 1;
+  }
+  fe inv; f_inv_fast(&FQ, &inv, &acc);
+  for (int i = size - 1; i >= 0; --i) {
+    const sched_pt sp = S->set[i];
+    aff_t* b = &S->a_bucks[sp.buck];
+    const aff_t* q = &bases[sp.base];
+    S->pending[sp.buck] = 0;
+    if (kind[i] == 3) continue;
+    if (kind[i] == 0) { b->x = q->x; b->y = q->y; if (sp.neg) f_neg(&FQ, &b->y, &q->y); continue; }
+    fe lambda, x3, y3, tt;
+    QMUL(&lambda, &inv, &t[i]); QMUL(&inv, &inv, &z[i]);
+    QSQR(&x3, &lambda); QSUB(&x3, &x3, &b->x); QSUB(&x3, &x3, &q->x);     /* doubling: q.x == b.x */
+    QSUB(&tt, &b->x, &x3); QMUL(&y3, &lambda, &tt); QSUB(&y3, &y3, &b->y);
+    b->x = x3; b->y = y3;
+  }
+  S->ptr = 0;
+}
+
+typedef struct {
+  const fe* ks; const aff_t* pts; size_t n;   /* the task's point group */
+  uint32_t w, c;
+  jac_t res;
+} win_task;
+
+static void run_window_task(win_task* T) {
+  const uint32_t c = T->c, nbk = 1u << (c - 1);
+  schedule_t S;
+  S.a_bucks = (aff_t*)calloc(nbk, sizeof(aff_t));
+  S.j_bucks = (jac_t*)malloc(sizeof(jac_t) * nbk);
+  S.pending = (uint8_t*)calloc(nbk, 1);
+  S.ptr = 0;
+  for (uint32_t b = 0; b < nbk; ++b) jac_set_id(&S.j_bucks[b]);
+  for (size_t i = 0; i < T->n; ++i) {
+    const int32_t d = booth_digit(&T->ks[i], T->w, c);
+    if (d == 0 || aff_is_id(&T->pts[i])) continue;
+    const uint32_t buck = (uint32_t)(d < 0 ? -d : d) - 1;
+    if (S.pending[buck]) {                                     /* greedy accumulation on the side bucket */
+      jac_madd_signed(&S.j_bucks[buck], &S.j_bucks[buck], &T->pts[i], d < 0);
+    } else {
+      S.set[S.ptr++] = (sched_pt){(uint32_t)i, buck, d < 0};
+      S.pending[buck] = 1;
+      if (S.ptr == SCHED_BATCH) sched_execute(&S, T->pts);
+    }
+  }
+  sched_execute(&S, T->pts);
+  jac_t run, acc; jac_set_id(&run); jac_set_id(&acc);
+  for (int b = (int)nbk - 1; b >= 0; --b) {                    /* summation by parts */
+    if (!jac_is_id(&S.j_bucks[b])) jac_add(&run, &run, &S.j_bucks[b]);
+    if (!aff_is_id(&S.a_bucks[b])) jac_madd(&run, &run, &S.a_bucks[b]);
+    jac_add(&acc, &acc, &run);
+  }
+  for (uint32_t i = 0; i < c * T->w; ++i) jac_double(&acc, &acc);
+  T->res = acc;
+  free(S.a_bucks); free(S.j_bucks); free(S.pending);
+}
+
+typedef struct { win_task* tasks; size_t count; size_t next; pthread_mutex_t mu; } task_pool;
+static void* pool_worker(void* arg) {
+  task_pool* P = (task_pool*)arg;
+  for (;;) {
+    pthread_mutex_lock(&P->mu);
+    const size_t k = P->next < P->count ? P->next++ : (size_t)-1;
+    pthread_mutex_unlock(&P->mu);
+    if (k == (size_t)-1) return NULL;
+    run_window_task(&P->tasks[k]);
+  }
+}
+
+/* groups = 0: as many point groups as keep `threads` busy (threads / windows, at least 1); groups = 1 is the
+ * halo2curves shape exactly (window tasks only). */
+int oracle_msm_best_ex(const uint8_t* scalars32_mont, const uint8_t* points64, size_t n, int threads, int groups,
+                       uint8_t* out96, uint32_t* info /* [c, windows, groups, threads used] or NULL */) {
+  if (n == 0) return 1;
+  if (threads < 1) threads = 1;
+  fe* ks = (fe*)malloc(sizeof(fe) * n);
+  {
+    int dt = threads; if ((size_t)dt > n) dt = (int)n;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * dt);
+    dm_job* dj = (dm_job*)malloc(sizeof(dm_job) * dt);
+    for (int t = 0; t < dt; ++t) {
+      dj[t] = (dm_job){scalars32_mont, ks, n * t / dt, n * (t + 1) / dt};
+      pthread_create(&th[t], NULL, dm_worker, &dj[t]);
+    }
+    for (int t = 0; t < dt; ++t) pthread_join(th[t], NULL);
+    free(th); free(dj);
+  }
+  uint32_t c;
+  if (groups < 1) groups = 0;
+  /* the window follows the size of a GROUP (each group is an MSM of its own) */
+  uint32_t W0 = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const size_t gn = groups > 0 ? (n + groups - 1) / groups : n;
+    if (gn < 4) c = 1; else if (gn < 32) c = 3; else c = (uint32_t)ceil(log((double)gn));
+    W0 = 254 / c + 1;
+    if (groups > 0) break;
+    groups = threads / (int)W0; if (groups < 1) groups = 1;
+    if ((size_t)groups > n) groups = (int)n;
+  }
+  const uint32_t W = W0;
+  const size_t count = (size_t)groups * W;
+  win_task* tasks = (win_task*)malloc(sizeof(win_task) * count);
+  const aff_t* pts = (const aff_t*)points64;
+  for (int g = 0; g < groups; ++g) {
+    const size_t lo = n * g / groups, hi = n * (g + 1) / groups;
+    for (uint32_t w = 0; w < W; ++w)                           /* high windows first: they cost the most doublings */
+      tasks[(size_t)g * W + w] = (win_task){ks + lo, pts + lo, hi - lo, W - 1 - w, c, {{{0}}}};
+  }
+  task_pool P = {tasks, count, 0, PTHREAD_MUTEX_INITIALIZER};
+  int used = threads; if ((size_t)used > count) used = (int)count;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * used);
+  for (int t = 0; t < used; ++t) pthread_create(&th[t], NULL, pool_worker, &P);
+  for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+  jac_t total; jac_set_id(&total);
+  for (size_t k = 0; k < count; ++k) jac_add(&total, &total, &tasks[k].res);
+  jac_normalise(&total, &total);
+  memcpy(out96, &total, 96);
+  if (info) { info[0] = c; info[1] = W; info[2] = (uint32_t)groups; info[3] = (uint32_t)used; }
+  free(th); free(tasks); free(ks);
+  return 0;
+}
+
+int oracle_msm_best(const uint8_t* scalars32_mont, const uint8_t* points64, size_t n, int threads, uint8_t* out96) {
+  return oracle_msm_best_ex(scalars32_mont, points64, n, threads, 0, out96, NULL);
 }
 
 /* sum_i k_i * P_i by plain double-and-add (the definition); for small n only. */

@@ -46,3 +46,30 @@ def test_gpu_with_cpu(cfg, msm_pkg, n, split):
     assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(co.msm_best(sb, pb, n, 2))
     z = int.from_bytes(out[64:96], "little")
     assert z in (0, o.MONT_R % o.P)
+
+
+def test_after_sort_callback_fires_before_accumulation_ends(cfg, msm_pkg):
+    """gpu_msm_h2c_sync's condvar hook (msm.rs:237-241, 306-312): the callback runs exactly once, after the sort of
+    THIS MSM and -- at a size where accumulation takes over a millisecond -- while accumulation is still pending."""
+    from oracle import c_oracle as co
+    n = 1 << 20
+    pts, sc = co.gen_instance(0xB2540000 + 77, n)
+    ref = msm_pkg.gpu_msm_h2c(sc, pts, cfg)       # also grows the workspaces: allocations synchronise the device
+    fired = []
+    out = msm_pkg.gpu_msm_h2c_sync(sc, pts, lambda: fired.append(1), cfg)
+    assert fired == [1]
+    assert cfg.timings().reserved2[1] == 1.0          # accumulate had not completed when the callback ran
+    assert out == ref
+    assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(co.msm_best(sc, pts, n))
+    # no callback: same result, state reads "no callback ran"
+    out2 = msm_pkg.gpu_msm_h2c_sync(sc, pts, None, cfg)
+    assert out2 == out and cfg.timings().reserved2[1] == -1.0
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 15, 16, 17, 40])
+def test_msm_best_size_dispatch_agrees_on_both_sides(cfg, msm_pkg, n):
+    """Sizes below msm_amd_cpu_dispatch_below() take the host bucket method, the rest the GPU: same answers."""
+    pts, sc = small_instance(300 + n, n)
+    sc[0] = 0
+    sb, pb = h2c_instance_bytes(pts, sc)
+    assert o.decode_jacobian_mont_le(msm_pkg.msm_best(sb, pb, cfg)) == o.msm_naive(sc, pts)

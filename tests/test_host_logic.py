@@ -75,3 +75,47 @@ def test_no_device_means_loud_failure(msm_pkg):
     assert ei.value.status in (msm_pkg.DEVICE_NOT_FOUND, msm_pkg.LIBRARY_ERROR)
     with pytest.raises(msm_pkg.MsmError):
         msm_pkg.get_global_metal_config()
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    """include/msm_amd.h is the FFI contract: it must be valid C99 on its own (no C++-isms, no HIP or torch types),
+    and a C translation unit using every documented call form must compile against it."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "use_header.c"
+    src.write_text(r'''
+#include "msm_amd.h"
+static void on_sorted(void* user) { *(int*)user = 1; }
+int drive(const void* scalars, const void* points, size_t n, unsigned char out[96]) {
+  msm_amd_ctx* ctx = 0;
+  msm_amd_timings t;
+  int fired = 0;
+  int rc = msm_amd_init(-1, &ctx);
+  if (rc != MSM_AMD_OK) return rc;
+  rc = msm_amd_gpu_msm_h2c(ctx, scalars, points, n, out);
+  if (rc == MSM_AMD_OK) rc = msm_amd_gpu_msm_h2c_sync(ctx, scalars, points, n, on_sorted, &fired, out);
+  if (rc == MSM_AMD_OK) rc = msm_amd_msm(ctx, MSM_AMD_SCALAR_MONT_LE, MSM_AMD_POINT_H2C_AFFINE, scalars, points, n, out);
+  if (rc == MSM_AMD_OK) rc = msm_amd_msm_best(ctx, scalars, points, n, out);
+  if (rc == MSM_AMD_OK) rc = msm_amd_last_timings(ctx, &t);
+  msm_amd_destroy(ctx);
+  return rc + (int)msm_amd_cpu_dispatch_below() * 0 + fired * 0;
+}
+''')
+    for std in ("-std=c99", "-std=c11"):
+        subprocess.check_call([gcc, std, "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c",
+                               str(src), "-o", str(tmp_path / "use_header.o")])
+    # and as C++ (the extern "C" guard)
+    gxx = shutil.which("g++")
+    if gxx:
+        subprocess.check_call([gxx, "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c++",
+                               "-c", str(src), "-o", str(tmp_path / "use_header_cpp.o")])
+
+
+def test_cpu_dispatch_threshold_is_small(msm_pkg):
+    """msm_best's size dispatch (msm.rs:440-444) re-tuned for MI355X: the reference's 2^17 would send every realistic
+    instance to the CPU; here only sizes below the measured crossover (a handful of points) are computed on the host."""
+    t = msm_pkg.lib().msm_amd_cpu_dispatch_below()
+    assert 0 <= t <= 1024
