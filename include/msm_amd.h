@@ -80,7 +80,8 @@ typedef struct msm_amd_timings {
   float accumulate_kernel_ms;   /* accumulate_kernel alone (events directly around its launch) */
   float reserved2[3];           /* [0] = work items of the last instance's accumulate grid (exact below 2^24)
                                    [1] = 1 if bucket accumulation had not finished yet when the after_sort
-                                         callback of msm_amd_gpu_msm_h2c_sync fired, 0 if it had, -1 if no callback ran */
+                                         callback of msm_amd_gpu_msm_h2c_sync fired, 0 if it had, -1 if no callback ran
+                                   [2] = device time (ms) from that callback to the end of bucket accumulation */
 } msm_amd_timings;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -124,9 +125,18 @@ int msm_amd_metal_msm_ark(msm_amd_ctx* ctx, const void* points, const void* scal
 int msm_amd_msm(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const void* scalars, const void* points,
                 size_t n, void* out96);
 /* The instance loop of gpu_profiler / benches (gpu_profiler.rs:104-106, msm_benchmark.rs:29-34):
- * n_inst independent MSMs; out = n_inst x 96 B. */
+ * n_inst independent MSMs; out = n_inst x 96 B.  Instance i + 1 is uploaded while instance i computes.  With
+ * MSM_AMD_POINT_PREPARED / MSM_AMD_POINT_TABLES the points array holds device pointers / table handles (see
+ * below) and only the scalars are uploaded. */
 int msm_amd_msm_batch(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
                       const void* const* scalars, const void* const* points, const size_t* n, void* out);
+
+/* Page-lock a caller buffer so that the host-buffer entry points above upload it by DMA at PCIe rate and without
+ * blocking the calling thread (pageable memory is staged by the runtime at about half that rate).  Meant for
+ * long-lived inputs such as the bases of an SRS, which the reference re-uploads on every call (msm.rs:152-153).
+ * The memory must stay valid and in place until msm_amd_host_unregister (or msm_amd_destroy). */
+int msm_amd_host_register(msm_amd_ctx* ctx, const void* ptr, size_t bytes);
+int msm_amd_host_unregister(msm_amd_ctx* ctx, const void* ptr);
 
 /* ---- hybrid front-end ----------------------------------------------------------------------- */
 /* msm_best::<G1Affine, ..>(scalars, points) -> G1 (msm.rs:424-445): filter_zeros (drop zero scalars when at

@@ -33,7 +33,7 @@ def op_is_point(op):
 EXPORTS = [
     "msm_amd_init", "msm_amd_init_reusable", "msm_amd_get_global", "msm_amd_destroy", "msm_amd_strerror",
     "msm_amd_last_error", "msm_amd_set_window_size", "msm_amd_auto_window_size", "msm_amd_gpu_msm_h2c",
-    "msm_amd_gpu_msm_h2c_sync", "msm_amd_cpu_dispatch_below",
+    "msm_amd_gpu_msm_h2c_sync", "msm_amd_cpu_dispatch_below", "msm_amd_host_register", "msm_amd_host_unregister",
     "msm_amd_metal_msm_ark", "msm_amd_msm", "msm_amd_msm_batch", "msm_amd_msm_best", "msm_amd_gpu_with_cpu",
     "msm_amd_reference_split", "msm_amd_msm_device",
     "msm_amd_msm_batch_device", "msm_amd_submit_batch_device", "msm_amd_wait_batch", "msm_amd_device_alloc", "msm_amd_device_free", "msm_amd_copy_to_device",
@@ -118,6 +118,8 @@ def _lib():
         L.msm_amd_gpu_msm_h2c.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
         L.msm_amd_metal_msm_ark.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
         L.msm_amd_gpu_msm_h2c_sync.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, AFTER_SORT_FN, c_void_p, c_void_p]
+        L.msm_amd_host_register.argtypes = [c_void_p, c_void_p, c_size_t]
+        L.msm_amd_host_unregister.argtypes = [c_void_p, c_void_p]
         L.msm_amd_cpu_dispatch_below.argtypes = []
         L.msm_amd_cpu_dispatch_below.restype = c_size_t
         L.msm_amd_msm.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
@@ -208,7 +210,10 @@ class MsmConfig:
                   point_layout=POINT_H2C_AFFINE):
         k = len(ns)
         sp = (c_void_p * k)(*[ctypes.cast(ctypes.c_char_p(s), c_void_p) for s in scalars_list])
-        pp = (c_void_p * k)(*[ctypes.cast(ctypes.c_char_p(p), c_void_p) for p in points_list])
+        if point_layout in (POINT_PREPARED, POINT_TABLES):    # device pointers / table handles, not host bytes
+            pp = (c_void_p * k)(*points_list)
+        else:
+            pp = (c_void_p * k)(*[ctypes.cast(ctypes.c_char_p(p), c_void_p) for p in points_list])
         nn = (c_size_t * k)(*ns)
         out = ctypes.create_string_buffer(96 * k)
         self._check(_lib().msm_amd_msm_batch(self.h, scalar_layout, point_layout, k, sp, pp, nn, out))
@@ -241,6 +246,14 @@ class MsmConfig:
         ticket, out, k = handle
         self._check(_lib().msm_amd_wait_batch(self.h, ticket))
         return [out.raw[96 * i:96 * i + 96] for i in range(k)]
+
+    def host_register(self, data: bytes):
+        """Page-lock the memory of a bytes object (keep it alive until host_unregister): DMA uploads."""
+        addr = ctypes.cast(ctypes.c_char_p(data), c_void_p)
+        self._check(_lib().msm_amd_host_register(self.h, addr, len(data)))
+
+    def host_unregister(self, data: bytes):
+        self._check(_lib().msm_amd_host_unregister(self.h, ctypes.cast(ctypes.c_char_p(data), c_void_p)))
 
     # ---- device memory ---------------------------------------------------------------------
     def alloc(self, nbytes) -> int:

@@ -95,6 +95,9 @@ struct msm_amd_ctx {
   bool low_occ_accumulate = true;        // 2-wave accumulate variant (set from overlap_front; MSM_AMD_LOW_OCC overrides)
   uint32_t seq = 0;
   hipStream_t front_stream = nullptr;    // side stream: conversion, digits, sort, work-item planning
+  hipStream_t copy_stream = nullptr;     // host-buffer entry points: uploads (DMA when the caller registered its buffers)
+  hipEvent_t uploaded[2] = {nullptr, nullptr};   // per staging set: the upload on copy_stream has finished
+  std::vector<std::pair<const void*, size_t>> host_regs;   // msm_amd_host_register
   bool overlap_reduce = true;            // MSM_AMD_OVERLAP_REDUCE=0 puts the reduction on the main stream
   bool overlap_front = true;             // MSM_AMD_OVERLAP_FRONT=0 puts the front end on the main stream
   Workspace ws[kWorkspaces];
@@ -107,6 +110,8 @@ struct msm_amd_ctx {
   Batch batches[kMaxBatches];
   msm_amd_timings timings{};
   float after_sort_state = -1.0f;   // timings.reserved2[1] of the next wait (see msm_amd_gpu_msm_h2c_sync)
+  float after_sort_lead_ms = 0.0f;  // timings.reserved2[2]: device time from the callback to the end of accumulation
+  hipEvent_t after_sort_mark = nullptr;   // recorded on the idle copy stream the moment the callback is about to run
 };
 
 namespace {
@@ -121,11 +126,31 @@ int fail(msm_amd_ctx* ctx, int status, const std::string& msg) {
 
 // Wait for everything this ctx has enqueued (error paths and set-up steps that reuse workspace 0).
 void drain_streams(msm_amd_ctx* ctx) {
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   (void)hipStreamSynchronize(ctx->front_stream);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->reduce_stream);
   (void)hipStreamSynchronize(ctx->reduce_stream2);
   (void)hipGetLastError();
+}
+
+// hipEventSynchronize may park the thread (it did, for more than a millisecond, inside a process that also hosts
+// torch's thread pools); the waits on the critical path of a blocking call poll the event for a few milliseconds
+// first and only then hand over to the runtime's wait.
+hipError_t wait_event(hipEvent_t ev) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return hipSuccess;
+    if (q != hipErrorNotReady) {
+      (void)hipGetLastError();
+      return q;
+    }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) break;
+    __builtin_ia32_pause();
+  }
+  (void)hipGetLastError();
+  return hipEventSynchronize(ev);
 }
 
 #define HIP_TRY(ctx, expr)                                                                        \
@@ -595,6 +620,7 @@ void accumulate_timings(msm_amd_ctx* ctx, InstanceSlot& s, const Plan& p, float 
   std::memcpy(&pc, s.h_partial + s.h_partial_cap, sizeof pc);
   T.reserved2[0] = (float)pc.total_items;   // work items (= lanes with work) of the last instance's accumulate grid
   T.reserved2[1] = ctx->after_sort_state;
+  T.reserved2[2] = ctx->after_sort_lead_ms;
 }
 
 // Batch of MSMs with device-resident inputs, in two halves so that callers can pipeline batches:
@@ -646,7 +672,7 @@ int wait_batch(msm_amd_ctx* ctx, int ticket) {
   ctx->timings = msm_amd_timings{};
   for (size_t i = 0; i < B.n_inst; ++i) {
     InstanceSlot& s = B.slots[i];
-    const hipError_t e = hipEventSynchronize(s.ev[EV_REDUCE]);
+    const hipError_t e = wait_event(s.ev[EV_REDUCE]);
     if (e != hipSuccess) {   // release the ticket on every exit: a failed wait must not block later submits
       drain_streams(ctx);
       B.active = false;
@@ -678,20 +704,28 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
     return fail(ctx, MSM_AMD_INPUT_ERROR, "null argument or empty batch");
   const size_t pb = point_bytes(point_layout);
   if (pb == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown point layout");
-  if (point_layout == MSM_AMD_POINT_PREPARED || point_layout == MSM_AMD_POINT_TABLES)
-    return fail(ctx, MSM_AMD_INPUT_ERROR, "prepared bases live on the device: use msm_amd_msm_prepared");
+  // prepared bases / window tables live on the device already: points[i] is the device pointer / table handle and
+  // only the scalars (32 bytes per point instead of 96) cross PCIe -- the repeated-SRS case
+  const bool dev_points = point_layout == MSM_AMD_POINT_PREPARED || point_layout == MSM_AMD_POINT_TABLES;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   for (size_t i = 0; i < n_inst; ++i)
     if (n[i] == 0 || !scalars[i] || !points[i]) return fail(ctx, MSM_AMD_INPUT_ERROR, "n == 0 or null pointer");
-  // Two staging sets: instance i + 1 is uploaded (and its front end enqueued) while instance i computes; the
-  // pageable-memory copies block the host, not the GPU.
-  int tickets[2] = {-1, -1};
+  // Two staging sets and up to three instances in flight.  Uploads run on their own stream (DMA for buffers the
+  // caller registered, msm_amd_host_register; the runtime's staged copy, which blocks this thread, for pageable
+  // memory): the upload of instance i waits -- on the GPU, not on the host -- until the front end of instance
+  // i - 2 has read the staging set (its EV_DIGITS event: conversion, convert_bases and digits are done), and the
+  // front-end stream of instance i waits for the upload.  The host only blocks to collect instance i - 3.
+  constexpr size_t kInflight = 3;
+  static_assert(kInflight <= (size_t)kMaxBatches, "one ticket per instance in flight");
+  std::vector<int> tickets(n_inst, -1);
   msm_amd_timings avg{};
+  size_t collected = 0;
   auto collect = [&](size_t i) {   // wait for instance i and fold its stage times into the running average
-    int rc = wait_batch(ctx, tickets[i & 1]);
+    int rc = wait_batch(ctx, tickets[i]);
+    tickets[i] = -1;
     if (rc) return rc;
     const msm_amd_timings& T = ctx->timings;
-    const float a = (float)i / (float)(i + 1), b = 1.0f / (float)(i + 1);
+    const float a = (float)collected / (float)(collected + 1), b = 1.0f / (float)(collected + 1);
     msm_amd_timings k = T;
     k.convert_ms = avg.convert_ms * a + T.convert_ms * b;
     k.digits_ms = avg.digits_ms * a + T.digits_ms * b;
@@ -701,7 +735,7 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
     k.reduce_ms = avg.reduce_ms * a + T.reduce_ms * b;
     k.final_ms = avg.final_ms * a + T.final_ms * b;
     k.total_gpu_ms = avg.total_gpu_ms * a + T.total_gpu_ms * b;
-    k.reserved = (uint32_t)(i + 1);
+    k.reserved = (uint32_t)(++collected);
     avg = k;
     return (int)MSM_AMD_OK;
   };
@@ -711,27 +745,44 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
       if (t >= 0) ctx->batches[t].active = false;
     return rc;
   };
+  {   // staging buffers are sized once, before anything is in flight (growing one would free memory in use)
+    size_t max_n = 0;
+    for (size_t i = 0; i < n_inst; ++i) max_n = std::max(max_n, n[i]);
+    int rc;
+    for (DeviceBuf* b : {&ctx->scratch_b, &ctx->scratch_b2})
+      if ((rc = ensure(ctx, *b, max_n * scalar_bytes(scalar_layout)))) return rc;
+    if (!dev_points)
+      for (DeviceBuf* b : {&ctx->scratch_c, &ctx->scratch_c2})
+        if ((rc = ensure(ctx, *b, max_n * pb))) return rc;
+  }
+  hipStream_t fs = ctx->overlap_front ? ctx->front_stream : ctx->stream;
   for (size_t i = 0; i < n_inst; ++i) {
+    int rc;
+    if (i >= kInflight && (rc = collect(i - kInflight))) return bail(rc);
     DeviceBuf& sbuf = (i & 1) ? ctx->scratch_b2 : ctx->scratch_b;
     DeviceBuf& pbuf = (i & 1) ? ctx->scratch_c2 : ctx->scratch_c;
-    int rc;
-    if ((rc = ensure(ctx, sbuf, n[i] * scalar_bytes(scalar_layout)))) return bail(rc);
-    if ((rc = ensure(ctx, pbuf, n[i] * pb))) return bail(rc);
-    // uploads go on the stream the front end runs on, so conversion / digits see them in order
-    hipStream_t up = ctx->overlap_front ? ctx->front_stream : ctx->stream;
-    hipError_t e = hipMemcpyAsync(sbuf.p, scalars[i], n[i] * scalar_bytes(scalar_layout), hipMemcpyHostToDevice, up);
-    if (e == hipSuccess) e = hipMemcpyAsync(pbuf.p, points[i], n[i] * pb, hipMemcpyHostToDevice, up);
+    hipError_t e = hipSuccess;
+    if (i >= 2)   // the staging set's previous reader
+      e = hipStreamWaitEvent(ctx->copy_stream, ctx->batches[tickets[i - 2]].slots[0].ev[EV_DIGITS], 0);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(sbuf.p, scalars[i], n[i] * scalar_bytes(scalar_layout), hipMemcpyHostToDevice,
+                         ctx->copy_stream);
+    if (e == hipSuccess && !dev_points)
+      e = hipMemcpyAsync(pbuf.p, points[i], n[i] * pb, hipMemcpyHostToDevice, ctx->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->uploaded[i & 1], ctx->copy_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(fs, ctx->uploaded[i & 1], 0);
     if (e != hipSuccess) return bail(fail(ctx, MSM_AMD_PIPELINE_ERROR, hipGetErrorString(e)));
     const void* ds = sbuf.p;
-    const void* dp = pbuf.p;
+    const void* dp = dev_points ? points[i] : pbuf.p;
     int ticket = -1;
     rc = submit_batch_device(ctx, scalar_layout, point_layout, 1, &ds, &dp, &n[i], (uint8_t*)out + i * 96, &ticket);
     if (rc) return bail(rc);
-    tickets[i & 1] = ticket;
-    if (i > 0 && (rc = collect(i - 1))) return bail(rc);   // frees the other staging set for instance i + 1
+    tickets[i] = ticket;
   }
-  int rc = collect(n_inst - 1);
-  if (rc) return bail(rc);
+  for (size_t i = n_inst > kInflight ? n_inst - kInflight : 0; i < n_inst; ++i) {
+    int rc = collect(i);
+    if (rc) return bail(rc);
+  }
   ctx->timings = avg;
   return MSM_AMD_OK;
 }
@@ -794,7 +845,10 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   bool ok = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_least) == hipSuccess &&
             hipStreamCreateWithPriority(&ctx->reduce_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipStreamCreateWithPriority(&ctx->reduce_stream2, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
-            hipStreamCreateWithPriority(&ctx->front_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
+            hipStreamCreateWithPriority(&ctx->front_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+            hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+            hipEventCreateWithFlags(&ctx->uploaded[0], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ctx->uploaded[1], hipEventDisableTiming) == hipSuccess;
   for (int k = 0; ok && k < kWorkspaces; ++k)
     ok = hipEventCreateWithFlags(&ctx->ws[k].front_done, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&ctx->ws[k].acc_done, hipEventDisableTiming) == hipSuccess &&
@@ -811,6 +865,9 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
     (void)hipStreamDestroy(ctx->reduce_stream);
     (void)hipStreamDestroy(ctx->reduce_stream2);
     (void)hipStreamDestroy(ctx->front_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+    (void)hipEventDestroy(ctx->uploaded[0]);
+    (void)hipEventDestroy(ctx->uploaded[1]);
     delete ctx;
     return rc;
   }
@@ -873,11 +930,49 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
       for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(s.ev[i]);
     if (s.h_partial) (void)hipHostFree(s.h_partial);
   }
+  if (ctx->after_sort_mark) (void)hipEventDestroy(ctx->after_sort_mark);
+  for (auto& r : ctx->host_regs) (void)hipHostUnregister(const_cast<void*>(r.first));   // left registered by the caller
+  (void)hipGetLastError();
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->reduce_stream);
   (void)hipStreamDestroy(ctx->reduce_stream2);
   (void)hipStreamDestroy(ctx->front_stream);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  for (hipEvent_t e : ctx->uploaded)
+    if (e) (void)hipEventDestroy(e);
   delete ctx;
+}
+
+// Page-locks a caller buffer for the life of the registration, so that the host-buffer entry points upload it by
+// DMA at PCIe rate and without blocking the calling thread (pageable memory is staged by the runtime at roughly
+// half that rate, on the calling thread).  Meant for long-lived inputs -- the bases of an SRS -- exactly the data
+// the reference re-uploads on every call (msm.rs:152-153).  The caller keeps the memory valid and in place until
+// msm_amd_host_unregister (or msm_amd_destroy).
+int msm_amd_host_register(msm_amd_ctx* ctx, const void* ptr, size_t bytes) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  if (!ptr || bytes == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "null pointer or empty range");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (auto& r : ctx->host_regs)
+    if (r.first == ptr) return fail(ctx, MSM_AMD_INPUT_ERROR, "range already registered");
+  HIP_TRY(ctx, hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault));
+  ctx->host_regs.emplace_back(ptr, bytes);
+  return MSM_AMD_OK;
+}
+
+int msm_amd_host_unregister(msm_amd_ctx* ctx, const void* ptr) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  for (size_t i = 0; i < ctx->host_regs.size(); ++i)
+    if (ctx->host_regs[i].first == ptr) {
+      HIP_TRY(ctx, hipSetDevice(ctx->device));
+      drain_streams(ctx);
+      (void)hipStreamSynchronize(ctx->copy_stream);
+      HIP_TRY(ctx, hipHostUnregister(const_cast<void*>(ptr)));
+      ctx->host_regs.erase(ctx->host_regs.begin() + (long)i);
+      return MSM_AMD_OK;
+    }
+  return fail(ctx, MSM_AMD_INPUT_ERROR, "range was not registered on this ctx");
 }
 
 int msm_amd_set_window_size(msm_amd_ctx* ctx, uint32_t window_size) {
@@ -927,19 +1022,31 @@ int msm_amd_gpu_msm_h2c_sync(msm_amd_ctx* ctx, const void* scalars, const void* 
   ctx->after_sort_state = -1.0f;
   if (after_sort) {
     InstanceSlot& s = ctx->batches[ticket].slots[0];
-    const hipError_t e = hipEventSynchronize(s.ev[EV_SORT]);   // sorted indices of this MSM exist (msm.rs:306-312)
+    const hipError_t e = wait_event(s.ev[EV_SORT]);   // sorted indices of this MSM exist (msm.rs:306-312)
     if (e != hipSuccess) {
       drain_streams(ctx);
       ctx->batches[ticket].active = false;
       return fail(ctx, MSM_AMD_PIPELINE_ERROR, std::string("hipEventSynchronize(sort): ") + hipGetErrorString(e));
     }
-    const hipError_t q = hipEventQuery(s.ev[EV_ACC]);
-    ctx->after_sort_state = q == hipErrorNotReady ? 1.0f : 0.0f;
-    (void)hipGetLastError();
+    // a GPU-clock mark of "now" on a stream that has nothing queued: after the MSM has finished, the device time
+    // from this mark to the end of bucket accumulation tells whether the callback ran while the GPU was still
+    // accumulating (positive) -- host-side event queries race with the runtime's own polling
+    if (!ctx->after_sort_mark) HIP_TRY(ctx, hipEventCreate(&ctx->after_sort_mark));
+    HIP_TRY(ctx, hipEventRecord(ctx->after_sort_mark, ctx->copy_stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->after_sort_mark));   // the runtime submits lazily: make the mark real now
     after_sort(user);
+    HIP_TRY(ctx, hipEventSynchronize(s.ev[EV_ACC]));
+    float lead = 0.0f;
+    if (hipEventElapsedTime(&lead, ctx->after_sort_mark, s.ev[EV_ACC]) != hipSuccess) {
+      (void)hipGetLastError();
+      lead = 0.0f;
+    }
+    ctx->after_sort_state = lead > 0.0f ? 1.0f : 0.0f;
+    ctx->after_sort_lead_ms = lead;
   }
   rc = wait_batch(ctx, ticket);
   ctx->after_sort_state = -1.0f;
+  ctx->after_sort_lead_ms = 0.0f;
   return rc;
 }
 

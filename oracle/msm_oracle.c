@@ -529,7 +529,9 @@ int oracle_msm_best_ex(const uint8_t* scalars32_mont, const uint8_t* points64, s
     if (gn < 4) c = 1; else if (gn < 32) c = 3; else c = (uint32_t)ceil(log((double)gn));
     W0 = 254 / c + 1;
     if (groups > 0) break;
-    groups = threads / (int)W0; if (groups < 1) groups = 1;
+    /* enough (group, window) tasks that the last round of the thread pool is well filled: >= 3 per thread */
+    groups = (3 * threads + (int)W0 - 1) / (int)W0; if (groups < 1) groups = 1;
+    if (threads == 1) groups = 1;
     if ((size_t)groups > n) groups = (int)n;
   }
   const uint32_t W = W0;

@@ -54,11 +54,14 @@ def test_after_sort_callback_fires_before_accumulation_ends(cfg, msm_pkg):
     from oracle import c_oracle as co
     n = 1 << 20
     pts, sc = co.gen_instance(0xB2540000 + 77, n)
-    ref = msm_pkg.gpu_msm_h2c(sc, pts, cfg)       # also grows the workspaces: allocations synchronise the device
-    fired = []
+    ref = msm_pkg.gpu_msm_h2c(sc, pts, cfg)
+    for _ in range(4):                            # steady state: every one of the ctx's four workspaces has been grown
+        assert msm_pkg.gpu_msm_h2c(sc, pts, cfg) == ref   # to this size (growing one frees and allocates device memory,
+    fired = []                                    # which synchronises the device in the middle of the enqueue)
     out = msm_pkg.gpu_msm_h2c_sync(sc, pts, lambda: fired.append(1), cfg)
     assert fired == [1]
-    assert cfg.timings().reserved2[1] == 1.0          # accumulate had not completed when the callback ran
+    t = cfg.timings()
+    assert t.reserved2[1] == 1.0 and t.reserved2[2] > 0.0, list(t.reserved2)   # device clock: accumulation ended AFTER the mark
     assert out == ref
     assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(co.msm_best(sc, pts, n))
     # no callback: same result, state reads "no callback ran"

@@ -169,3 +169,72 @@ def test_log24_ark_projective_dlog_identity(cfg, msm_pkg):
         cfg.free(ds)
         if d_proj is not None:
             cfg.free(d_proj)
+
+
+def test_headline_shape_two_batches_in_flight_dlog(cfg, msm_pkg):
+    """The bench's shape: 2 batches x 5 instances of 2^20 points in flight through submit_batch_device / wait_batch
+    (4 workspaces, 4 streams, both reduce streams busy).  Bases are dlog-structured, P_i = (a0 + i d) G, so every one
+    of the 10 results is checked against (sum k_i (a0 + i d)) G computed with big integers -- no MSM code on the
+    checking side."""
+    n, inst = 1 << 20, 5
+    rng = random.Random(31337)
+    r_inv = pow(o.MONT_R, -1, o.R_ORDER)
+    d_pts, params = [], []
+    d_sc = [[], []]
+    try:
+        for j in range(inst):
+            a0, d = rng.randrange(o.R_ORDER), rng.randrange(o.R_ORDER)
+            dp, ds = cfg.generate_instance(o.SEED_BASE + 900 + j, n, True)
+            pb, _ = co.dlog_instance(a0, d, cfg.to_host(ds, 32 * n), n)
+            cfg.to_device(dp, pb)
+            d_pts.append(dp)
+            d_sc[0].append(ds)
+            dp2, ds2 = cfg.generate_instance(o.SEED_BASE + 950 + j, n, True)   # second batch: other scalars
+            cfg.free(dp2)
+            d_sc[1].append(ds2)
+            params.append((a0, d))
+        ns = [n] * inst
+        h0 = cfg.submit_batch_device(d_sc[0], d_pts, ns)
+        h1 = cfg.submit_batch_device(d_sc[1], d_pts, ns)          # both batches in flight before any wait
+        outs = [cfg.wait_batch(h0), cfg.wait_batch(h1)]
+        for b in range(2):
+            for j in range(inst):
+                a0, d = params[j]
+                raw = cfg.to_host(d_sc[b][j], 32 * n)
+                s, base = 0, a0
+                for i in range(n):
+                    s += int.from_bytes(raw[32 * i:32 * i + 32], "little") * base
+                    base += d
+                s = s * r_inv % o.R_ORDER                          # scalars are Montgomery residues k R mod r
+                assert o.decode_jacobian_mont_le(outs[b][j]) == o.scalar_mul(s, o.GEN), (b, j)
+    finally:
+        for p in d_pts + d_sc[0] + d_sc[1]:
+            cfg.free(p)
+
+
+def test_registered_host_buffers_and_resident_bases_batch(cfg, msm_pkg):
+    """msm_amd_host_register (DMA uploads) and msm_amd_msm_batch with MSM_AMD_POINT_PREPARED (bases resident, only
+    scalars cross PCIe): same results as the plain host-buffer batch and as the CPU oracle."""
+    n, inst = 1 << 16, 3
+    data = [co.gen_instance(o.SEED_BASE + 40 + j, n) for j in range(inst)]
+    pts, scs = [d[0] for d in data], [d[1] for d in data]
+    ns = [n] * inst
+    plain = cfg.msm_batch(scs, pts, ns)
+    for b in pts + scs:
+        cfg.host_register(b)
+    try:
+        with pytest.raises(msm_pkg.MsmError):
+            cfg.host_register(pts[0])                              # registering twice is refused
+        assert cfg.msm_batch(scs, pts, ns) == plain
+        prepared = [cfg.bases_upload(p, n) for p in pts]
+        try:
+            assert cfg.msm_batch(scs, prepared, ns, point_layout=msm_pkg.POINT_PREPARED) == plain
+        finally:
+            for d in prepared:
+                cfg.free(d)
+    finally:
+        for b in pts + scs:
+            cfg.host_unregister(b)
+    with pytest.raises(msm_pkg.MsmError):
+        cfg.host_unregister(pts[0])
+    assert o.decode_jacobian_mont_le(plain[0]) == o.decode_jacobian_mont_le(co.msm_best(scs[0], pts[0], n))
