@@ -708,8 +708,18 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
   // only the scalars (32 bytes per point instead of 96) cross PCIe -- the repeated-SRS case
   const bool dev_points = point_layout == MSM_AMD_POINT_PREPARED || point_layout == MSM_AMD_POINT_TABLES;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  for (size_t i = 0; i < n_inst; ++i)
+  for (size_t i = 0; i < n_inst; ++i) {
     if (n[i] == 0 || !scalars[i] || !points[i]) return fail(ctx, MSM_AMD_INPUT_ERROR, "n == 0 or null pointer");
+    if (point_layout == MSM_AMD_POINT_PREPARED) {   // must really be device memory: a host array here would fault
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, points[i]) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(ctx, MSM_AMD_INPUT_ERROR,
+                    "MSM_AMD_POINT_PREPARED takes the device array written by msm_amd_bases_upload / "
+                    "msm_amd_bases_prepare_device, not a host buffer");
+      }
+    }
+  }
   // Two staging sets and up to three instances in flight.  Uploads run on their own stream (DMA for buffers the
   // caller registered, msm_amd_host_register; the runtime's staged copy, which blocks this thread, for pageable
   // memory): the upload of instance i waits -- on the GPU, not on the host -- until the front end of instance

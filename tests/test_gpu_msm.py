@@ -169,10 +169,13 @@ def test_persistent_bases_match_the_per_call_path(cfg, msm_pkg):
         (out2,) = cfg.msm_batch_device([d_sc], [handles[0]], [n], point_layout=msm_pkg.POINT_PREPARED)
         assert out2 == msm_pkg.gpu_msm_h2c(sb2, pb, cfg)
         cfg.free(d_sc)
-        # prepared arrays are device memory: the host-buffer entry point refuses the layout
+        # prepared arrays are device memory: a HOST point buffer under that layout is refused, not dereferenced
         with pytest.raises(msm_pkg.MsmError) as e:
             cfg.msm(sb, pb, n, point_layout=msm_pkg.POINT_PREPARED)
         assert e.value.status == msm_pkg.INPUT_ERROR
+        # host scalars + resident bases through the host-buffer batch entry point (only scalars cross PCIe)
+        assert cfg.msm_batch([sb, sb2], [handles[0], handles[1]], [n, n], point_layout=msm_pkg.POINT_PREPARED) == \
+            [want, out2]
     finally:
         for h in handles:
             cfg.free(h)
