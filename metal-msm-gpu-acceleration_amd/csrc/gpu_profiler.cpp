@@ -3,6 +3,8 @@
 //
 //   gpu_profiler [log_size=16] [num_instances=1] [mode=gpu] [retries=3] [parallel=false]
 //                [--seed S] [--device D] [--window C] [--layout h2c|ark] [--json] [--vec-dir DIR | --vec-cache]
+//                [--warmup N]   N untimed passes first (default 0, like the reference: its first timed pass then
+//                               includes the one-off growth of the device workspaces)
 //
 // Modes (gpu_profiler.rs:143-172)
 //   gpu       metal::msm::gpu_msm_h2c      -> msm_amd_gpu_msm_h2c (host buffers, upload included)
@@ -39,6 +41,7 @@ int main(int argc, char** argv) {
   std::vector<std::string> pos;
   uint64_t seed = 0xB2540000ull;
   int device = -1, window = 0;
+  unsigned warmup = 0;
   bool json = false;
   bool ark = false;   // --layout ark: ark_bn254 G1Projective points (96 B, z = one), config 5 of BASELINE.json
   bool use_vecs = false;   // --vec-dir DIR | --vec-cache: inputs come from / go to the reference's instance file
@@ -50,6 +53,7 @@ int main(int argc, char** argv) {
     else if (a == "--window" && i + 1 < argc) window = std::atoi(argv[++i]);
     else if (a == "--layout" && i + 1 < argc) ark = std::string(argv[++i]) == "ark";
     else if (a == "--json") json = true;
+    else if (a == "--warmup" && i + 1 < argc) warmup = (unsigned)std::strtoul(argv[++i], nullptr, 10);
     else if (a == "--vec-dir" && i + 1 < argc) { use_vecs = true; vec_dir = argv[++i]; }
     else if (a == "--vec-cache") use_vecs = true;   // $HOME/.msm_gpu_acceleration/msm_vecs, like the reference
     else pos.push_back(a);
@@ -189,8 +193,9 @@ int main(int argc, char** argv) {
   std::vector<const void*> sp(num_instances), pp(num_instances);
   std::vector<size_t> ns(num_instances, n);
 
-  const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned r = 0; r < retries; ++r) {
+  auto t0 = std::chrono::steady_clock::now();
+  for (unsigned r = 0; r < retries + warmup; ++r) {
+    if (r == warmup) t0 = std::chrono::steady_clock::now();
     if (mode == "gpu") {
       if (parallel) {
         for (unsigned j = 0; j < num_instances; ++j) { sp[j] = h_sc[j].data(); pp[j] = h_pts[j].data(); }

@@ -21,7 +21,11 @@ struct Plan {
   bool wide_digits;           // digits are u32 (c up to 24) instead of u16 (c <= 15)
   uint32_t lb, nb;            // bucket slots per window nb = 2^lb = max(2^(c-1), 8); slot i holds |digit| = i + 1
   uint32_t Q, chunk;          // sort: chunks per window, points per chunk
-  uint32_t hb, fb;            // sort: coarse / fine bits of the slot (hb + fb = lb)
+  uint32_t hb, mb, fb;        // sort: coarse / middle / fine bits of the slot (hb + mb + fb = lb; mb = 0: two passes)
+  uint32_t Q2;                // sort: chunks per coarse region in the middle pass
+  uint32_t tile_threads;      // workgroup size of the tiled scatter kernels
+  uint32_t tiled;             // sort: coarse / middle scatter stage a tile in LDS and write whole runs (tile_scatter)
+  uint32_t ballot;            // sort ranking: bit 0 coarse / middle passes, bit 1 pass 2 use the wave multisplit
   uint32_t front_threads;     // workgroup size of the sort / planning kernels (256..1024)
   uint32_t CH;                // accumulate: max points per work item (bucket chunk)
   uint32_t nseg, K;           // reduce: segments per window, bits of segment index (lb - 3)
@@ -43,6 +47,10 @@ struct SortBuffers {
   uint32_t* region_start;     // [W][2^hb + 1]
   uint32_t* tmp_idx;          // [W][n]        pass-1 output: index | sign << 31, grouped by coarse region
   uint16_t* tmp_fine;         // [W][n]        pass-1 output: fine digit
+  uint32_t* tmp_idx2;         // [W][n]        middle-pass output (three-level sort only)
+  uint16_t* tmp_fine2;        // [W][n]
+  uint32_t* mid_cnt;          // [W * 2^hb][Q2][2^mb]
+  uint32_t* region_start2;    // [W][2^(hb+mb) + 1]
   uint32_t* bucket_size;      // [W][nb]
   uint32_t* bucket_start;     // [W][nb]   offset inside the window's slice of `sorted`
   uint32_t* item_start;       // [W][nb]   first item id of the bucket inside its window

@@ -31,6 +31,7 @@ namespace {
 
 constexpr uint32_t kModulusBits = 254;   // limbs_conversion.rs:172, :344
 constexpr uint32_t kMinWindow = 3, kMaxWindow = 17;   // u16 digits up to 15, u32 digits for 16 and 17
+constexpr uint32_t kDefaultBallot = 1;                // sort ranking (Plan::ballot), chosen by profiles/r02_sort_ranking_ab.txt
 constexpr size_t kCpuDispatchBelow = 5;               // msm_best: see cpu_dispatch_below()
 
 struct DeviceBuf {
@@ -56,7 +57,7 @@ struct InstanceSlot {
 // whole instances on parallel streams was tried and gained little: a resident accumulate grid keeps the
 // 1024-thread sort workgroups of the other stream from being placed at all.)
 struct Workspace {
-  DeviceBuf digits, coarse_cnt, region_start, tmp_idx, tmp_fine, bsize, bstart, istart, win_items, size_bins, sorted,
+  DeviceBuf digits, coarse_cnt, region_start, tmp_idx, tmp_fine, tmp_idx2, tmp_fine2, mid_cnt, region_start2, bsize, bstart, istart, win_items, size_bins, sorted,
       order, multi_list, counters, bases29, buckets, item_partials, S, T, tree_tmp, partial, conv_scalars, conv_points,
       conv_tmp;
   hipEvent_t front_done = nullptr;    // front stream: sorted indices / work items of this workspace are ready
@@ -224,22 +225,61 @@ Plan make_plan(size_t n_scalars, uint32_t c, uint32_t windows = 0) {
   Q = std::max(1u, std::min(Q, max_q));
   p.Q = Q;
   p.chunk = (uint32_t)((((n + Q - 1) / Q) + 63) & ~(size_t)63);
-  // coarse regions of ~16 k points so that pass 2 sorts a region inside LDS; at least 2 fine bits.  At most 128
-  // regions: beyond that pass 1 keeps too many partially written lines open (2^24 points: 10.2 ms with 1024
-  // regions, 6.0 ms with 128, whose 131 k-point regions pass 2 scatters directly inside an L2-sized range).
-  // (the single long window of the table pipeline needs regions that fit LDS more than it needs few regions)
-  uint32_t hb = 0;
-  const uint32_t hb_cap = windows ? 10u : 7u;
-  while (hb + 2 < p.lb && hb < hb_cap && (n >> hb) > 16384) ++hb;
+  // Sort geometry.  Pass 2 sorts a region inside LDS, so the coarse passes must cut a window into regions of
+  // ~16 k entries: T = ceil(log2(n / 16384)) coarse bits.  Up to 7 bits (128 regions) one coarse pass does it
+  // (every per-call plan up to 2^21 points); beyond that the bits are split over TWO coarse passes of <= 6 bits
+  // each (hb + mb, three-level sort): one pass with 1024 regions keeps too many partially written lines open
+  // (2^24 points: 10.2 ms), and 128 regions of 131 k entries force pass 2 to scatter in global memory (6.0 ms).
+  uint32_t T = 0;
+  while (T + 2 < p.lb && (n >> T) > 16384) ++T;
+  uint32_t hb = T, mb = 0;
+  if (T > 7) {
+    hb = (T + 1) / 2;
+    mb = T - hb;
+  }
   if (const char* e = std::getenv("MSM_AMD_HB")) {   // experiments: coarse bits of the two-pass sort
     const int v = std::atoi(e);
-    if (v >= 0 && (uint32_t)v + 2 <= p.lb) hb = (uint32_t)v;
+    if (v >= 0 && (uint32_t)v + 2 <= p.lb) {
+      hb = (uint32_t)v;
+      mb = 0;
+    }
+  }
+  if (const char* e = std::getenv("MSM_AMD_MB")) {   // experiments: middle-pass bits
+    const int v = std::atoi(e);
+    if (v >= 0 && hb + (uint32_t)v + 2 <= p.lb) mb = (uint32_t)v;
   }
   p.hb = hb;
-  p.fb = p.lb - hb;
+  p.mb = mb;
+  p.fb = p.lb - hb - mb;
   if (p.fb > 10) {   // the fine histogram is scanned with one bin per thread (<= 1024 bins)
+    const uint32_t extra = p.fb - 10;
     p.fb = 10;
-    p.hb = p.lb - 10;
+    if (p.mb || p.hb + extra > 7) p.mb += extra; else p.hb += extra;
+  }
+  // what pass 1 leaves in the u16 tmp_fine is mb + fb bits
+  while (p.mb + p.fb > 16) {
+    ++p.hb;
+    --p.mb;
+  }
+  // Tile-staged scatter (k_sort.hip tile_scatter): 26 % less sort time for ONE huge instance (2^24 points: 7.0 ->
+  // 5.2 ms with 1024-thread workgroups), but its 60 VGPRs x 1024 threads cannot be placed beside a resident
+  // accumulate grid, so inside a pipeline of instances it loses (headline 695 -> 643 MSM/s; with 512 threads: no
+  // difference to the direct scatter).  Used where the sort is not hidden behind another instance's accumulation:
+  // per-call plans that need the three-level sort (2^22 points and more).
+  p.tiled = (p.mb != 0 && windows == 0) ? 1u : 0u;
+  if (const char* e = std::getenv("MSM_AMD_TILED")) p.tiled = std::atoi(e) != 0;
+  p.tile_threads = 1024;
+  if (const char* e = std::getenv("MSM_AMD_TILE_THREADS")) {
+    const int v = std::atoi(e);
+    if (v == 256 || v == 512 || v == 1024) p.tile_threads = (uint32_t)v;
+  }
+  p.ballot = kDefaultBallot;
+  if (const char* e = std::getenv("MSM_AMD_BALLOT")) p.ballot = (uint32_t)std::atoi(e) & 3u;
+  p.Q2 = 1;
+  if (p.mb) {
+    const uint32_t regions = p.W << p.hb;
+    p.Q2 = std::max(1u, 1024u / regions);
+    while (p.Q2 > 1 && (n >> p.hb) / p.Q2 < 4096) p.Q2 >>= 1;
   }
   // accumulate work items: at most CH points each; buckets longer than CH are cut into several items whose partial
   // sums the combine kernels add up (one extra full addition per cut, and a second affine+affine start).  Uniform
@@ -491,6 +531,12 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   if ((rc = ensure(ctx, w.region_start, (size_t)p.W * ((1u << p.hb) + 1) * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.tmp_idx, (size_t)p.W * n * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.tmp_fine, (size_t)p.W * n * sizeof(uint16_t)))) return rc;
+  if (p.mb) {
+    if ((rc = ensure(ctx, w.tmp_idx2, (size_t)p.W * n * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, w.tmp_fine2, (size_t)p.W * n * sizeof(uint16_t)))) return rc;
+    if ((rc = ensure(ctx, w.mid_cnt, ((size_t)p.W << p.hb) * p.Q2 * (1u << p.mb) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, w.region_start2, (size_t)p.W * ((1u << (p.hb + p.mb)) + 1) * sizeof(uint32_t)))) return rc;
+  }
   if ((rc = ensure(ctx, w.bsize, p.total_buckets * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.bstart, p.total_buckets * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.istart, p.total_buckets * sizeof(uint32_t)))) return rc;
@@ -511,6 +557,10 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   sb.region_start = (uint32_t*)w.region_start.p;
   sb.tmp_idx = (uint32_t*)w.tmp_idx.p;
   sb.tmp_fine = (uint16_t*)w.tmp_fine.p;
+  sb.tmp_idx2 = (uint32_t*)w.tmp_idx2.p;
+  sb.tmp_fine2 = (uint16_t*)w.tmp_fine2.p;
+  sb.mid_cnt = (uint32_t*)w.mid_cnt.p;
+  sb.region_start2 = (uint32_t*)w.region_start2.p;
   sb.bucket_size = (uint32_t*)w.bsize.p;
   sb.bucket_start = (uint32_t*)w.bstart.p;
   sb.item_start = (uint32_t*)w.istart.p;
@@ -917,7 +967,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->reduce_stream2);
   for (int k = 0; k < kWorkspaces; ++k) {
     Workspace& w = ctx->ws[k];
-    DeviceBuf* bufs[] = {&w.digits, &w.coarse_cnt, &w.region_start, &w.tmp_idx, &w.tmp_fine, &w.bsize, &w.bstart, &w.istart, &w.win_items, &w.size_bins, &w.sorted,
+    DeviceBuf* bufs[] = {&w.digits, &w.coarse_cnt, &w.region_start, &w.tmp_idx, &w.tmp_fine, &w.tmp_idx2, &w.tmp_fine2, &w.mid_cnt, &w.region_start2, &w.bsize, &w.bstart, &w.istart, &w.win_items, &w.size_bins, &w.sorted,
                          &w.order, &w.multi_list, &w.counters, &w.bases29, &w.buckets, &w.item_partials, &w.S, &w.T,
                          &w.tree_tmp, &w.partial, &w.conv_scalars, &w.conv_points, &w.conv_tmp};
     for (DeviceBuf* b : bufs)
