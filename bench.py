@@ -36,6 +36,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the drop-in-caller figures (host slices, lone calls)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend of the result gather: nccl (= RCCL over xGMI, the measured configuration) "
+                         "or gloo (rehearsal of the N-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="REHEARSAL ONLY (with --backend gloo): ranks share the visible GPUs (local_rank %% visible); "
+                         "the line is marked and is not a scaling measurement")
     ap.add_argument("--window", type=int, default=0, help="force the window size (0 = the library's automatic choice)")
     ap.add_argument("--precomputed-tables", action="store_true",
                     help="NOT the headline: window tables 2^(c w) P precomputed once per set of bases (SURVEY §8f N4), "
@@ -91,15 +97,27 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     visible = torch.cuda.device_count()     # does not initialise the GPU
-    if visible <= local_rank or visible < world:
+    shared = args.allow_shared_gpu and args.backend == "gloo"
+    if args.allow_shared_gpu and not shared:
+        raise SystemExit("bench.py: --allow-shared-gpu is a rehearsal switch and needs --backend gloo "
+                         "(RCCL does not run two ranks on one device)")
+    if not shared and (visible <= local_rank or visible < world):
         raise SystemExit(f"bench.py: rank {rank} of {world} needs GPU {local_rank} but only {visible} GPU(s) are "
                          f"visible: --gpus {world} cannot run here")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" IS RCCL on ROCm
+    if visible < 1:
+        raise SystemExit("bench.py: no GPU visible")
+    gpu_index = local_rank % visible if shared else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" IS RCCL on ROCm
+        coll_dev = dev
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        coll_dev = torch.device("cpu")
 
     m = importlib.import_module(PKG)
-    cfg = m.setup_metal_state(local_rank)          # fails loudly without a gfx950 device
+    cfg = m.setup_metal_state(gpu_index)           # fails loudly without a gfx950 device
     if args.window:
         cfg.set_window_size(args.window)
     n = 1 << args.log_size
@@ -121,7 +139,7 @@ def main(argv=None):
         d_pts = [cfg.bases_prepare_device(dp, n) for dp in d_pts]
         point_layout = m.POINT_PREPARED
 
-    gatherer = mg.ResultGatherer(dist, dev, inst)
+    gatherer = mg.ResultGatherer(dist, coll_dev, inst)
 
     def finish(handle):
         outs = cfg.wait_batch(handle)                    # host Horner pass of the batch
@@ -170,11 +188,11 @@ def main(argv=None):
     allr = gatherer.fetch()                              # every rank holds every instance's result
     if allr[rank * inst:(rank + 1) * inst] != outs:
         raise SystemExit(f"rank {rank}: gathered results differ from the local ones")
-    ids = torch.full((1,), rank, dtype=torch.int32, device=dev)
-    seen = torch.empty(world, dtype=torch.int32, device=dev)
+    ids = torch.full((1,), rank, dtype=torch.int32, device=coll_dev)
+    seen = torch.empty(world, dtype=torch.int32, device=coll_dev)
     dist.all_gather_into_tensor(seen, ids)
     ranks_seen = len(set(int(x) for x in seen.cpu().tolist()))
-    te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    te = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     dist.all_reduce(te, op=dist.ReduceOp.MAX)
     elapsed = float(te.item())
     if ranks_seen != world or len(allr) != world * inst or any(r == bytes(96) for r in allr):
@@ -263,7 +281,7 @@ def main(argv=None):
                     parity_ok = False
         if rank == 0 and world == 1 and not args.no_extras and point_layout == m.POINT_H2C_AFFINE:
             extras = drop_in_caller_figures(m, cfg, h_sc, h_pts, n, inst, outs)
-    okt = torch.tensor([1 if parity_ok else 0], dtype=torch.int32, device=dev)
+    okt = torch.tensor([1 if parity_ok else 0], dtype=torch.int32, device=coll_dev)
     dist.all_reduce(okt, op=dist.ReduceOp.MIN)
     if int(okt.item()) != 1:
         raise SystemExit("PARITY FAILURE on at least one rank (GPU != CPU oracle)")
@@ -284,12 +302,16 @@ def main(argv=None):
             "dtype": "u32x8 (256-bit Montgomery integer)",
             "data": "synthetic",
             "rccl_ranks_seen": ranks_seen,
+            "collective": "rccl" if args.backend == "nccl" else "gloo (rehearsal, not RCCL)",
             "parity": ("bit-exact vs the CPU oracle on every rank's own instances" if not args.no_cpu_baseline
                        else "not checked in this run (--no-cpu-baseline)"),
             "config": {"workload": f"log_size={args.log_size}, {inst} instances per GPU, h2c BN254 G1 "
                                    f"(gpu_msm_h2c pipeline, window {window})",
                        "instances_per_gpu": inst, "log_size": args.log_size, "window_size": window,
-                       "parallelism": f"instance-sharded x{world}, RCCL all_gather of 96-byte results",
+                       "parallelism": f"instance-sharded x{world}, "
+                                      + ("RCCL all_gather of 96-byte results" if args.backend == "nccl" else
+                                         "gloo all_gather of 96-byte results (REHEARSAL"
+                                         + (", ranks share a GPU: not a scaling measurement)" if shared else ")")),
                        "pipelining": "step k+1 is submitted before step k's results are collected (submit/wait API)",
                        "bases": "precomputed window tables (built once, NOT the headline configuration)"
                                 if args.precomputed_tables else
