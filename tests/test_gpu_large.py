@@ -238,3 +238,59 @@ def test_registered_host_buffers_and_resident_bases_batch(cfg, msm_pkg):
     with pytest.raises(msm_pkg.MsmError):
         cfg.host_unregister(pts[0])
     assert o.decode_jacobian_mont_le(plain[0]) == o.decode_jacobian_mont_le(co.msm_best(scs[0], pts[0], n))
+
+
+@pytest.mark.parametrize("env", [
+    {"MSM_AMD_HB": "3", "MSM_AMD_MB": "3"},                          # three-level sort forced at a small size
+    {"MSM_AMD_HB": "4", "MSM_AMD_MB": "4", "MSM_AMD_TILED": "1"},    # + tile-staged scatter
+    {"MSM_AMD_TILED": "1", "MSM_AMD_TILE_THREADS": "512"},
+    {"MSM_AMD_BALLOT": "0"}, {"MSM_AMD_BALLOT": "3"},                # ranking: LDS atomics only / wave multisplit everywhere
+    {"MSM_AMD_CH": "16"},                                            # every bucket above 16 points is split and combined
+])
+def test_sort_and_plan_variants_give_identical_results(cfg, env):
+    """The plan knobs are read per call: every sort / ranking / work-item variant must return the same bytes as the
+    default plan, on uniform scalars and on a skewed instance (all scalars equal: one bucket per window holds all
+    points, one sort region holds the whole window)."""
+    import os
+    n = 1 << 17
+    dp, ds = cfg.generate_instance(o.SEED_BASE + 1234, n, True)
+    k = 0x1F0D1E2C3B4A59687766554433221100FFEEDDCCBBAA99887766554433221100 % o.R_ORDER
+    d_eq = cfg.alloc(32 * n)
+    cfg.to_device(d_eq, o.encode_scalar_h2c(k) * n)
+    try:
+        want = cfg.msm_batch_device([ds, d_eq], [dp, dp], [n, n])
+        old = {key: os.environ.get(key) for key in env}
+        os.environ.update(env)
+        try:
+            got = cfg.msm_batch_device([ds, d_eq], [dp, dp], [n, n])
+        finally:
+            for key, v in old.items():
+                if v is None:
+                    os.environ.pop(key, None)
+                else:
+                    os.environ[key] = v
+        assert got == want
+    finally:
+        cfg.free(dp)
+        cfg.free(ds)
+        cfg.free(d_eq)
+
+
+def test_log22_three_level_sort_uniform_and_skewed(cfg):
+    """2^22 points take the three-level sort and the tile-staged scatter by default: uniform scalars against the CPU
+    oracle, and all-equal scalars (k * sum of the points) where one coarse region, one middle region and one bucket
+    per window hold everything."""
+    n = 1 << 22
+    dp, ds = cfg.generate_instance(o.SEED_BASE + 2222, n, True)
+    try:
+        pb, sb = cfg.to_host(dp, 64 * n), cfg.to_host(ds, 32 * n)
+        out = cfg.msm_batch_device([ds], [dp], [n])[0]
+        assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(co.msm_best(sb, pb, n))
+        k = 0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF % o.R_ORDER
+        eq = o.encode_scalar_h2c(k) * n
+        cfg.to_device(ds, eq)
+        out = cfg.msm_batch_device([ds], [dp], [n])[0]
+        assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(co.msm_best(eq, pb, n))
+    finally:
+        cfg.free(dp)
+        cfg.free(ds)
