@@ -13,7 +13,9 @@
 //
 // Value bounds maintained for every point that is stored or carried in a register between additions
 // (multiples of p; see the bounds contract in bn254_fq29.hip.h):
-//      X < 9.5 p      Y < 6 p      ZZ, ZZZ < 2 p      limbs 0..7 < 2^29 + 8
+//      X < 10 p      Y < 6 p      ZZ < 2.8 p      ZZZ < 2 p      limbs 0..7 < 2^29 + 8
+// (pti_mmadd sets the X and ZZ figures: its R < 12.1 p and ZZ3 = P^2 with P < 17.1 p).  tools/fq29_bounds.py
+// re-derives every bound below by interval arithmetic and checks that no 64-bit column sum can overflow.
 // The exceptional cases (equal points -> doubling, opposite points -> identity) are detected with the
 // one-limb filter Fq29::maybe_zero, confirmed exactly (Fq29::is_zero_exact) and resolved by pti_double / the
 // identity, all on the same limbs.
@@ -54,7 +56,7 @@ MSM_HD PtI pti_identity() {
 MSM_HD PtI pti_from_affi(const AffI& q) {   // q must not be the identity
   PtI r;
   r.x = q.x;
-  r.y = q.y;
+  r.y = Fq29::norm(q.y);   // q.y may be an un-normalised negation (accumulate_kernel); a stored point is normalised
   r.zz = Fq29::one();
   r.zzz = Fq29::one();
   return r;
@@ -148,8 +150,10 @@ MSM_HD PtI pti_madd(const PtI& p, const AffI& q) {
   const fe29 RR = Fq29::sqr(R);
   PtI r;
   r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.5 p
-  const fe29 T = Fq29::norm(Fq29::sub<K16E30>(Q, r.x));                                   // < 17.2 p
-  r.y = Fq29::mul2(R, T, p.y, Fq29::neg(PPP));   // R*T - Y1*PPP in one reduction              // < 1.2 p
+  // T and -PPP stay un-normalised (limbs < 2^31 / 2^30.5): their partners R and Y1 in the double product are
+  // normalised, and tools/fq29_bounds.py checks that no column of R*T + Y1*(-PPP) can reach 2^64
+  const fe29 T = Fq29::sub<K16E30>(Q, r.x);                                               // < 17.2 p
+  r.y = Fq29::mul2(R, T, p.y, Fq29::neg_wide(PPP));   // R*T - Y1*PPP in one reduction         // < 1.2 p
   r.zz = Fq29::mul(p.zz, PP);
   r.zzz = Fq29::mul(p.zzz, PPP);
   return r;
@@ -161,7 +165,7 @@ MSM_HD PtI pti_madd(const PtI& p, const AffI& q) {
 // The result obeys the same bounds as pti_madd's.
 MSM_HD PtI pti_mmadd(const fe29& px, const fe29& py, const AffI& q) {
   const fe29 P = Fq29::norm(Fq29::sub<K16E30>(q.x, px));   // < 17.1 p
-  const fe29 R = Fq29::norm(Fq29::sub<K8E30>(q.y, py));    // < 12.1 p
+  const fe29 R = Fq29::norm(Fq29::sub<K8E30>(q.y, py));    // < 12.1 p (q.y may be an un-normalised negation, py not)
   if (Fq29::maybe_zero(P, 18)) {
     if (Fq29::is_zero_exact(P)) {   // same x: either q == p (double) or q == -p (identity)
       if (Fq29::is_zero_exact(R)) return pti_double(pti_from_affi(q));
@@ -173,10 +177,10 @@ MSM_HD PtI pti_mmadd(const fe29& px, const fe29& py, const AffI& q) {
   const fe29 Q = Fq29::mul(px, PP);
   const fe29 RR = Fq29::sqr(R);
   PtI r;
-  r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.5 p
+  r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.9 p
   const fe29 T = Fq29::norm(Fq29::sub<K16E30>(Q, r.x));                                   // < 17.2 p
-  r.y = Fq29::mul2(R, T, py, Fq29::neg(PPP));    // R*T - Y1*PPP in one reduction              // < 1.2 p
-  r.zz = PP;
+  r.y = Fq29::mul2(R, T, py, Fq29::neg_wide(PPP));   // R*T - Y1*PPP in one reduction          // < 1.2 p
+  r.zz = PP;                                                                              // < 2.8 p
   r.zzz = PPP;
   return r;
 }
@@ -201,8 +205,8 @@ MSM_HD PtI pti_add_nz(const PtI& p, const PtI& q) {
   const fe29 RR = Fq29::sqr(R);
   PtI r;
   r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.2 p
-  const fe29 T = Fq29::norm(Fq29::sub<K16E30>(Q, r.x));                                   // < 17.1 p
-  r.y = Fq29::mul2(R, T, S1, Fq29::neg(PPP));    // R*T - S1*PPP in one reduction              // < 1.2 p
+  const fe29 T = Fq29::sub<K16E30>(Q, r.x);      // un-normalised, like -PPP (see pti_madd)   // < 17.1 p
+  r.y = Fq29::mul2(R, T, S1, Fq29::neg_wide(PPP));    // R*T - S1*PPP in one reduction         // < 1.2 p
   r.zz = Fq29::mul(Fq29::mul(p.zz, q.zz), PP);
   r.zzz = Fq29::mul(Fq29::mul(p.zzz, q.zzz), PPP);
   return r;

@@ -123,6 +123,9 @@ struct Fq29 {
 
   // -a (mod p) for a with limbs <= 2^30 - 2 and value < ~3.9 p; result < 4 p, limbs 0..7 < 2^29 + 8.
   MSM_HD static fe29 neg(const fe29& a) { return norm(sub<K4E30>(zero(), a)); }
+  // The same without the carry round: limbs up to 2^30.5.  Only as ONE operand of a multiplication whose other
+  // operand is normalised (every use is checked by tools/fq29_bounds.py).
+  MSM_HD static fe29 neg_wide(const fe29& a) { return sub<K4E30>(zero(), a); }
 
   // One parallel carry round: limbs 0..7 < 2^29 + 8 afterwards, limb 8 absorbs the top carry.
   MSM_HD static fe29 norm(const fe29& a) {

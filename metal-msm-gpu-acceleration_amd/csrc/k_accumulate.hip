@@ -64,7 +64,9 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
     cur_idx = next_idx;
     if (i + 2 < cnt) next_idx = idx[i + 2];
     {
-      const fe29 ny = Fq29::neg(cur.y);
+      // -y without the carry round (limbs < 2^30.5): y only ever multiplies the normalised ZZZ1, or enters the
+      // lifted subtraction of pti_mmadd (bounds: tools/fq29_bounds.py)
+      const fe29 ny = Fq29::neg_wide(cur.y);
 #pragma unroll
       for (int l = 0; l < 9; ++l) cur.y.l[l] = negate ? ny.l[l] : cur.y.l[l];
     }

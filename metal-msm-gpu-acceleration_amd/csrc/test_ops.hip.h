@@ -109,8 +109,8 @@ MSM_HD void run_test_op(int op, const u256* a, const u256* b, u256* out, uint32_
       qa.x = q.x;
       qa.y = q.y;
       AffI pi = affi_from_ext(pa), qi = affi_from_ext(qa);
-      pi.y = Fq29::neg(pi.y);
-      qi.y = Fq29::neg(qi.y);
+      pi.y = Fq29::neg(pi.y);         // the accumulator's y: normalised when the point was stored (pti_from_affi)
+      qi.y = Fq29::neg_wide(qi.y);    // the incoming base's y: un-normalised negation, as in accumulate_kernel
       PtI acc = pti_mmadd(pi.x, pi.y, qi);
       for (int i = 0; i < 3; ++i) acc = pti_is_identity(acc) ? pti_from_affi(qi) : pti_madd(acc, qi);
       r = pti_to_ext(acc);
