@@ -21,10 +21,11 @@
 //
 //   reduce stream (k_accumulate.hip, k_reduce.hip)
 //   combine_small/big     sum the partials of split buckets into buckets
-//   reduce_seg_kernel     buckets -> S[W][nseg], T[W][nseg]   (running sums over segments of 8 slots)
-//   reduce_tree_*_kernel  S, T -> partial[W][K+2]  (plain sums + K bit-subset sums per window, external Jacobian;
-//                         one wide workgroup per sum, or two levels of one-wave workgroups for long windows)
-//   host                  Horner over the bit positions of the (K+2) * W partial points (msm_host.hip host_combine)
+//   sum_groups_kernel     buckets -> row sums R[W][2^H] and column sums C[W][2^L] of the slot matrix (slot = hi * 2^L
+//                         + lo), in log8 levels of groups of 8: plain sums, every bucket added exactly twice
+//   reduce_bits_kernel    R, C -> partial[W][lb + 1]  (bit-subset sums of C and of R + the window total, external
+//                         Jacobian): window value = total + sum_k 2^k CB_k + 2^L sum_k 2^k RB_k
+//   host                  Horner over the bit positions of the (lb + 1) * W partial points (msm_host.hip host_combine)
 //
 // This replaces the reference's prepare_buckets_indices / sort_buckets (CPU rayon sort!) /
 // bucket_wise_accumulation / sum_reduction_partial+final kernels (src/metal/shader/msm.h.metal:17-562,
@@ -36,7 +37,7 @@
 //     then binary-searches bucket boundaries per threadgroup, msm.h.metal:61-73,130-131);
 //   * work is balanced by ordering work items by length, not by splitting pairs evenly over threads and
 //     merging bucket boundaries through threadgroup memory (msm.h.metal:229-314);
-//   * window sums use running sums over 8-slot segments followed by bit-subset tree sums, which
+//   * window sums use plain row / column sums of the slot matrix followed by bit-subset sums over them, which
 //     needs no scalar multiplications (the reference multiplies sums by counts with double-and-add in
 //     every combine, msm.h.metal:429-430);
 //   * the three streams work on three different instances at any time (msm_host.hip enqueue_msm).

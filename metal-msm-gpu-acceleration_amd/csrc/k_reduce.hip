@@ -1,141 +1,84 @@
 // Stage 4: window reduction kernels.  See device_common.hip.h for the pipeline overview.
+//
+// Slot i of a window holds the bucket of digit magnitude i + 1, so the window value is  sum_i (i + 1) X[i].  With
+// the slot index written as  i = hi * 2^L + lo  (L = ceil(lb / 2) column bits, H = lb - L row bits):
+//     sum_i (i + 1) X[i] = sum_i X[i]  +  sum_lo lo * C[lo]  +  2^L * sum_hi hi * R[hi]
+//     R[hi] = sum_lo X[hi, lo]  (row sums)        C[lo] = sum_hi X[hi, lo]  (column sums)
+// Row and column sums are PLAIN sums: every bucket is added exactly twice, in independent chains of at most 7
+// additions (sum_groups_kernel, groups of 8, log8 levels), instead of the running-sum pair "sum += X; sos += sum"
+// (two dependent additions per bucket) followed by bit-subset tree sums over the segment sums (another 0.9 per
+// bucket) that round 1 used: 2.0 instead of 2.9 full additions per bucket, and chains half as long.  The weights
+// lo and hi are applied the same way as before: bit-subset sums over the 2^L column sums and the 2^H row sums
+// (reduce_bits_kernel: tiny), whose powers of two the host Horner pass supplies with its doublings.
+// Replaces sum_reduction_partial / sum_reduction_final (msm.h.metal:319-562), whose combine step needs a scalar
+// multiplication per merge.
 #include "device_common.hip.h"
 #include "launch.h"
 
 namespace msm_amd {
 
-// ------------------------------------------------------------------------------------------------
-// Stage 4a: per-segment running sums.  Slot i of a window holds the bucket of digit magnitude i + 1.  For
-// segment s (slots 8s .. 8s+7):   S[w][s] = sum_j X[8s+j]     T[w][s] = sum_j j * X[8s+j]
-// so that  sum_i (i+1) X[i] = sum_s (T[s] + S[s]) + 8 * sum_s s*S[s].   Replaces sum_reduction_partial
-// (msm.h.metal:319-461), whose combine step needs a scalar multiplication per merge.
-__global__ void __launch_bounds__(64)
-reduce_seg_kernel(const PtI* __restrict__ buckets, const uint32_t* __restrict__ bucket_size, uint32_t total_segs,
-                  PtI* __restrict__ S, PtI* __restrict__ T) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= total_segs) return;
-  // bucket_size != nullptr: an empty bucket (no work item ever wrote it) holds stale memory and counts as the
-  // identity -- the bucket matrix is not cleared per MSM.  The size is re-read per slot (an L2 hit) rather than
-  // kept as a mask: one more live register would push the kernel over the next allocation granule.
-  const bool sized = bucket_size != nullptr;   // wave-uniform
-  // Two accumulators plus an operand and the temporaries of an addition need ~195 VGPRs.  Both running values are
-  // parked in LDS between additions, so every addition has two operands that die in it (like the tree kernels:
-  // <= 160 VGPRs) and a wave fits into the registers two resident accumulate waves (2 x 176 of 512) leave free.
-  __shared__ PtI park_sum[64];
-  __shared__ PtI park_sos[64];
-  store_pti(&park_sum[threadIdx.x], pti_identity());
-  store_pti(&park_sos[threadIdx.x], pti_identity());
-#pragma unroll 1
-  for (int j = kSeg - 1; j >= 0; --j) {
-    if (!sized || bucket_size[s * kSeg + j] != 0) {
-      const PtI sum = pti_add(load_pti(&park_sum[threadIdx.x]), load_pti(&buckets[s * kSeg + j]));
-      store_pti(&park_sum[threadIdx.x], sum);
-    }
-    asm volatile("" ::: "memory");   // keep the LDS reloads below the addition above (it is the point of parking)
-    if (j != 0) {
-      const PtI sos = pti_add(load_pti(&park_sos[threadIdx.x]), load_pti(&park_sum[threadIdx.x]));
-      store_pti(&park_sos[threadIdx.x], sos);
-    }
-    asm volatile("" ::: "memory");
-  }
-  store_pti(&S[s], load_pti(&park_sum[threadIdx.x]));
-  store_pti(&T[s], load_pti(&park_sos[threadIdx.x]));
-}
+// One job of a group-sum launch:  dst[row][q] = sum_{j < group, q*group + j < len} src[row_base(row) + (q*group + j) * elem_stride]
+//   row_base(row) = (row / rows_per_window) * window_stride + (row % rows_per_window) * row_stride
+// valid (level 1 only; same indexing as src): 0 = the slot was never written (the bucket matrix is not cleared per
+// MSM) and counts as the identity.
+struct GroupJob {
+  const PtI* src;
+  const uint32_t* valid;
+  PtI* dst;
+  size_t window_stride;
+  uint32_t total_rows, rows_per_window, row_stride, elem_stride, len, group, out_len;
+  uint32_t outputs;   // total_rows * out_len
+};
 
-// Stage 4b: tree sums, in two levels of ONE-WAVE workgroups (64 lanes, <= 160 VGPRs): a workgroup of several
-// waves can only be placed on a CU where every SIMD has room for its waves at once, which next to a resident
-// accumulate grid (2 x 176 VGPRs per SIMD) never happens before that grid drains; single waves slot in anywhere.
-//   level 1  grid = (K + 2, W, parts): slice `part` of sum k of window w -> tree_tmp[w][k][part]
-//            k == K : sum_s T[w][s]      k == K + 1 : sum_s S[w][s]      k < K : sum over segments s with bit k set
-//            of S[w][s]   (K = lb - 3 bits of segment index)
-//   level 2  grid = (K + 2, W): partial[w][k] = sum_part tree_tmp[w][k][part], converted to the external form
-// The host then evaluates  W_w = partial[w][K] + partial[w][K+1] + 8 * sum_k 2^k partial[w][k]  inside one Horner
-// pass over all bit positions (replaces sum_reduction_final msm.h.metal:463-562 and the doublings of
-// final_accumulation.rs:19-39).
-__device__ __forceinline__ PtI wave_tree_sum(PtI acc, PtI* sh) {
-  store_pti(&sh[threadIdx.x], acc);
-  __syncthreads();
-#pragma unroll 1
-  for (uint32_t stride = 32; stride >= 1; stride >>= 1) {
-    if (threadIdx.x < stride) {
-      const PtI a = load_pti(&sh[threadIdx.x]);
-      const PtI b2 = load_pti(&sh[threadIdx.x + stride]);
-      store_pti(&sh[threadIdx.x], pti_add(a, b2));
-    }
-    __syncthreads();
-  }
-  return load_pti(&sh[0]);
-}
-
+// The row-sum job and the column-sum job of one level in ONE launch (they are independent; a launch costs more
+// queueing behind the resident accumulate grid than the additions themselves).  One lane per output; both operands
+// of every addition die in it (<= 168 VGPRs).
 __global__ void __launch_bounds__(64)
-reduce_tree_kernel(const PtI* __restrict__ S, const PtI* __restrict__ T, uint32_t nseg, uint32_t K,
-                   PtI* __restrict__ tree_tmp) {
-  __shared__ PtI sh[64];
-  const uint32_t k = blockIdx.x, w = blockIdx.y, parts = gridDim.z;
-  const PtI* Sw = S + (size_t)w * nseg;
-  const PtI* Tw = T + (size_t)w * nseg;
-  PtI acc = pti_identity();
-  if (k >= K) {
-    // slot i carries weight i + 1:  sum_i (i+1) X[i] = sum_s T[s] + sum_s S[s] + 8 sum_s s S[s]
-    const PtI* src = (k == K) ? Tw : Sw;
-    const uint32_t len = nseg / parts, first = blockIdx.z * len;
-#pragma unroll 1
-    for (uint32_t s = first + threadIdx.x; s < first + len; s += 64) acc = pti_add(acc, load_pti(&src[s]));
-  } else {
-    const uint32_t half = nseg >> 1;
-    const uint32_t lowmask = (1u << k) - 1u;
-    const uint32_t len = half / parts, first = blockIdx.z * len;
-#pragma unroll 1
-    for (uint32_t j = first + threadIdx.x; j < first + len; j += 64) {
-      const uint32_t s = ((j & ~lowmask) << 1) | (1u << k) | (j & lowmask);
-      acc = pti_add(acc, load_pti(&Sw[s]));
-    }
-  }
-  const PtI sum = wave_tree_sum(acc, sh);
-  if (threadIdx.x == 0) store_pti(&tree_tmp[((size_t)w * (K + 2) + k) * parts + blockIdx.z], sum);
-}
-
-__global__ void __launch_bounds__(64)
-reduce_tree_final_kernel(const PtI* __restrict__ tree_tmp, uint32_t parts, uint32_t K, Jacobian* __restrict__ partial) {
-  __shared__ PtI sh[64];
-  const uint32_t k = blockIdx.x, w = blockIdx.y;
-  const PtI* src = tree_tmp + ((size_t)w * (K + 2) + k) * parts;
+sum_groups_kernel(GroupJob j0, GroupJob j1) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = t >= j0.outputs;
+  const GroupJob& J = second ? j1 : j0;
+  if (second) t -= j0.outputs;
+  if (t >= J.outputs) return;
+  const uint32_t row = t / J.out_len, q = t - row * J.out_len;
+  const size_t base = (size_t)(row / J.rows_per_window) * J.window_stride + (size_t)(row % J.rows_per_window) * J.row_stride;
+  const uint32_t first = q * J.group;
+  const uint32_t cnt = min(J.group, J.len - first);
   PtI acc = pti_identity();
 #pragma unroll 1
-  for (uint32_t i = threadIdx.x; i < parts; i += 64) acc = pti_add(acc, load_pti(&src[i]));
-  const PtI sum = wave_tree_sum(acc, sh);
-  // the host Horner pass works on the external 32-bit-limb form
-  if (threadIdx.x == 0) store_jac(&partial[(size_t)w * (K + 2) + k], pti_to_ext(sum));
+  for (uint32_t j = 0; j < cnt; ++j) {
+    const size_t at = base + (size_t)(first + j) * J.elem_stride;
+    if (J.valid == nullptr || J.valid[at] != 0) acc = pti_add(acc, load_pti(&J.src[at]));
+  }
+  store_pti(&J.dst[t], acc);
 }
 
-// Per-call pipeline (windows of <= 2^14 slots, at most 4 segments per thread): one 512-thread workgroup per
-// (sum, window) does both levels at once and writes the external form directly -- one launch less and, measured,
-// 1.5 % more MSM/s than the two-level form above, whose purpose is the long single window of the table pipeline.
-// grid = (K + 2, W), dynamic LDS = blockDim.x * 144 bytes.
+// grid = (lb + 1, W), one workgroup (a power of two of threads, 64..512) per sum:
+//   k < L      : sum of the column sums C[w][i] with bit k of i set
+//   L <= k < lb: sum of the row sums R[w][i] with bit k - L of i set
+//   k == lb    : sum of all row sums = the window total
+// written in the external Jacobian form to out[w * (lb + 1) + k].
 __global__ void __launch_bounds__(512)
-reduce_tree_wide_kernel(const PtI* __restrict__ S, const PtI* __restrict__ T, uint32_t nseg,
-                   uint32_t K, Jacobian* __restrict__ partial) {
+reduce_bits_kernel(const PtI* __restrict__ C, const PtI* __restrict__ R, uint32_t L, uint32_t H,
+                   Jacobian* __restrict__ out) {
   extern __shared__ uint32_t lds_u32[];
   PtI* sh = reinterpret_cast<PtI*>(lds_u32);
-  const uint32_t k = blockIdx.x, w = blockIdx.y;
-  const PtI* Sw = S + (size_t)w * nseg;
-  const PtI* Tw = T + (size_t)w * nseg;
+  const uint32_t k = blockIdx.x, w = blockIdx.y, lb = L + H;
+  const bool cols = k < L;
+  const uint32_t len = cols ? (1u << L) : (1u << H);
+  const PtI* Vw = (cols ? C : R) + (size_t)w * len;
   PtI acc = pti_identity();
-  if (k >= K) {
-    // slot i carries weight i + 1:  sum_i (i+1) X[i] = sum_s T[s] + sum_s S[s] + 8 sum_s s S[s];
-    // the two plain sums get a workgroup each (k == K: T, k == K + 1: S) to keep the critical path short
-    const PtI* src = (k == K) ? Tw : Sw;
-    const uint32_t len = nseg / gridDim.z, first = blockIdx.z * len;
+  if (k == lb) {
 #pragma unroll 1
-    for (uint32_t s = first + threadIdx.x; s < first + len; s += blockDim.x) acc = pti_add(acc, load_pti(&src[s]));
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) acc = pti_add(acc, load_pti(&Vw[i]));
   } else {
-    const uint32_t half = nseg >> 1;
-    const uint32_t lowmask = (1u << k) - 1u;
-    const uint32_t len = half / gridDim.z, first = blockIdx.z * len;
+    const uint32_t bit = cols ? k : k - L;
+    const uint32_t half = len >> 1;
+    const uint32_t lowmask = (1u << bit) - 1u;
 #pragma unroll 1
-    for (uint32_t j = first + threadIdx.x; j < first + len; j += blockDim.x) {
-      const uint32_t s = ((j & ~lowmask) << 1) | (1u << k) | (j & lowmask);
-      acc = pti_add(acc, load_pti(&Sw[s]));
+    for (uint32_t j = threadIdx.x; j < half; j += blockDim.x) {
+      const uint32_t i = ((j & ~lowmask) << 1) | (1u << bit) | (j & lowmask);
+      acc = pti_add(acc, load_pti(&Vw[i]));
     }
   }
   store_pti(&sh[threadIdx.x], acc);
@@ -150,33 +93,96 @@ reduce_tree_wide_kernel(const PtI* __restrict__ S, const PtI* __restrict__ T, ui
     __syncthreads();
   }
   // the host Horner pass works on the external 32-bit-limb form
-  if (threadIdx.x == 0)
-    store_jac(&partial[((size_t)w * (K + 2) + k) * gridDim.z + blockIdx.z], pti_to_ext(load_pti(&sh[0])));
+  if (threadIdx.x == 0) store_jac(&out[(size_t)w * (lb + 1) + k], pti_to_ext(load_pti(&sh[0])));
+}
+
+static uint32_t reduce_bits_threads(uint32_t lb) {
+  const uint32_t longest = 1u << ((lb + 1) / 2);
+  uint32_t t = 64;
+  while (t < 512 && t < longest / 2) t <<= 1;
+  return t;
 }
 
 int reduce_set_attributes(const char** failed) {
-  if (hipFuncSetAttribute((const void*)reduce_tree_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute((const void*)reduce_bits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                           160 * 1024) != hipSuccess) {
     (void)hipGetLastError();
-    *failed = "reduce_tree_wide_kernel";
+    *failed = "reduce_bits_kernel";
     return 1;
   }
   return 0;
 }
 
-void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, const uint32_t* bucket_size, PtI* S, PtI* T,
-                   PtI* tree_tmp, Jacobian* partial) {
-  hipLaunchKernelGGL(reduce_seg_kernel, dim3((unsigned)((p.total_segs + 63) / 64)), dim3(64), 0, st, buckets,
-                     bucket_size, (uint32_t)p.total_segs, S, T);
-  if (p.tree_wide_threads) {
-    hipLaunchKernelGGL(reduce_tree_wide_kernel, dim3(p.K + 2, p.W, 1), dim3(p.tree_wide_threads),
-                       p.tree_wide_threads * sizeof(PtI), st, (const PtI*)S, (const PtI*)T, p.nseg, p.K, partial);
-    return;
+constexpr uint32_t kGroup = 16;   // additions per lane and level: chains of 15, like the 8-slot running sums they replace
+
+// Elements of scratch one family (rows or columns) needs per window: all levels of the group sums.
+size_t reduce_scratch_elems(uint32_t lb) {
+  const uint32_t L = (lb + 1) / 2, H = lb - L;
+  size_t need = 0;
+  for (int fam = 0; fam < 2; ++fam) {
+    const size_t rows = (size_t)1 << (fam ? L : H);
+    uint32_t len = 1u << (fam ? H : L);
+    size_t s = 0;
+    while (len > 1) {
+      len = (len + kGroup - 1) / kGroup;
+      s += rows * len;
+    }
+    if (s == 0) s = rows;
+    need = std::max(need, s);
   }
-  hipLaunchKernelGGL(reduce_tree_kernel, dim3(p.K + 2, p.W, p.tree_parts), dim3(64), 0, st, (const PtI*)S,
-                     (const PtI*)T, p.nseg, p.K, tree_tmp);
-  hipLaunchKernelGGL(reduce_tree_final_kernel, dim3(p.K + 2, p.W), dim3(64), 0, st, (const PtI*)tree_tmp,
-                     p.tree_parts, p.K, partial);
+  return need;
+}
+
+// partial[w][0 .. L-1]      bit sums of the column sums (weights 2^k)
+// partial[w][L .. L+H-1]    bit sums of the row sums    (weights 2^(L + k))
+// partial[w][lb]            sum of all buckets of the window (weight 1)
+void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, const uint32_t* bucket_size, PtI* S, PtI* T,
+                   PtI* /*tree_tmp*/, Jacobian* partial) {
+  const uint32_t L = p.red_L, H = p.red_H;
+  const uint32_t ncols = 1u << L, nrows = 1u << H;
+  // family 0: row sums R[w][hi] (scratch S), family 1: column sums C[w][lo] (scratch T)
+  GroupJob job[2];
+  PtI* next_dst[2] = {S, T};
+  for (int fam = 0; fam < 2; ++fam) {
+    GroupJob& J = job[fam];
+    J.src = buckets;
+    J.valid = bucket_size;
+    J.window_stride = p.nb;
+    J.rows_per_window = fam ? ncols : nrows;
+    J.total_rows = p.W * J.rows_per_window;
+    J.row_stride = fam ? 1u : ncols;
+    J.elem_stride = fam ? ncols : 1u;
+    J.len = fam ? nrows : ncols;
+  }
+  while (job[0].len > 1 || job[1].len > 1) {
+    for (int fam = 0; fam < 2; ++fam) {
+      GroupJob& J = job[fam];
+      if (J.len > 1) {
+        J.group = std::min(J.len, kGroup);
+        J.out_len = (J.len + J.group - 1) / J.group;
+        J.outputs = J.total_rows * J.out_len;
+        J.dst = next_dst[fam];
+      } else {
+        J.outputs = 0;   // this family is done
+      }
+    }
+    const size_t outputs = (size_t)job[0].outputs + job[1].outputs;
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)((outputs + 63) / 64)), dim3(64), 0, st, job[0], job[1]);
+    for (int fam = 0; fam < 2; ++fam) {   // the next level reads what this one wrote: contiguous [W * rows][out_len]
+      GroupJob& J = job[fam];
+      if (J.outputs == 0) continue;
+      J.src = J.dst;
+      J.valid = nullptr;
+      J.window_stride = (size_t)J.rows_per_window * J.out_len;
+      J.row_stride = J.out_len;
+      J.elem_stride = 1;
+      J.len = J.out_len;
+      next_dst[fam] = J.dst + J.outputs;
+    }
+  }
+  // job[fam].src now points at [W][rows] sums
+  hipLaunchKernelGGL(reduce_bits_kernel, dim3(p.lb + 1, p.W), dim3(reduce_bits_threads(p.lb)),
+                     reduce_bits_threads(p.lb) * sizeof(PtI), st, job[1].src, job[0].src, L, H, partial);
 }
 
 }  // namespace msm_amd

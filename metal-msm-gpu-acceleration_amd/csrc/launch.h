@@ -28,9 +28,7 @@ struct Plan {
   uint32_t ballot;            // sort ranking: bit 0 coarse / middle passes, bit 1 pass 2 use the wave multisplit
   uint32_t front_threads;     // workgroup size of the sort / planning kernels (256..1024)
   uint32_t CH;                // accumulate: max points per work item (bucket chunk)
-  uint32_t nseg, K;           // reduce: segments per window, bits of segment index (lb - 3)
-  uint32_t tree_parts;        // reduce_tree: one-wave slices per (sum, window) (two-level form)
-  uint32_t tree_wide_threads; // != 0: single-level form with this many threads per (sum, window) instead
+  uint32_t red_L, red_H;      // reduce: column / row bits of the slot index (L = ceil(lb / 2), H = lb - L)
   size_t total_buckets, total_segs, partial_count, max_items;
 };
 
@@ -79,6 +77,7 @@ void launch_combine(hipStream_t st, const Plan& p, const SortBuffers& b, PtI* bu
 
 // k_reduce.hip
 int reduce_set_attributes(const char** failed);
+size_t reduce_scratch_elems(uint32_t lb);   // PtI elements of S and of T per window
 // bucket_size: [W][nb] point counts (zero = the bucket was never written and counts as the identity), or nullptr
 // when every bucket holds a valid point (stage entry point sum_reduction)
 void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, const uint32_t* bucket_size, PtI* S, PtI* T,

@@ -296,47 +296,27 @@ Plan make_plan(size_t n_scalars, uint32_t c, uint32_t windows = 0) {
     if (v >= 16 && v <= 512 && (v & (v - 1)) == 0) ch = (uint32_t)v;
   }
   p.CH = ch;
-  p.nseg = p.nb >> kSegLog;
-  p.K = p.lb - kSegLog;
+  p.red_L = (p.lb + 1) / 2;
+  p.red_H = p.lb - p.red_L;
   p.total_buckets = (size_t)p.W * p.nb;
-  p.total_segs = (size_t)p.W * p.nseg;
+  p.total_segs = (size_t)p.W * reduce_scratch_elems(p.lb);   // scratch elements of each of the two sum families
   p.max_items = p.total_buckets + ((size_t)p.W * n) / ch + 1;
-  // tree sums: one 64..512-thread workgroup per (sum, window) while that means at most 4 segments per thread
-  // (every per-call plan), else two levels of one-wave slices (the single long window of the table pipeline)
-  p.tree_parts = 1;
-  p.tree_wide_threads = 0;
-  if (p.nseg / 2 <= 4 * 512) {
-    uint32_t t = 64;
-    while (t < 512 && t < std::max(1u, p.nseg / 2)) t <<= 1;
-    p.tree_wide_threads = t;
-  } else {
-    while ((p.nseg / 2) / p.tree_parts > 4 * 64) p.tree_parts <<= 1;
-  }
-  p.partial_count = (size_t)p.W * (p.K + 2);
+  p.partial_count = (size_t)p.W * (p.lb + 1);
   return p;
 }
 
 // Geometry of the window reduction alone (stage entry point sum_reduction).
 Plan make_reduce_plan(uint32_t lb, uint32_t W) {
   Plan p{};
-  p.c = lb + kSegLog + 1;   // only used to space bit positions in host_combine (one window at a time)
+  p.c = lb + 1;   // only used to space bit positions in host_combine (one window at a time)
   p.W = W;
   p.lb = lb;
   p.nb = 1u << lb;
-  p.nseg = p.nb >> kSegLog;
-  p.K = lb - kSegLog;
+  p.red_L = (lb + 1) / 2;
+  p.red_H = lb - p.red_L;
   p.total_buckets = (size_t)p.W * p.nb;
-  p.total_segs = (size_t)p.W * p.nseg;
-  p.tree_parts = 1;
-  p.tree_wide_threads = 0;
-  if (p.nseg / 2 <= 4 * 512) {
-    uint32_t t = 64;
-    while (t < 512 && t < std::max(1u, p.nseg / 2)) t <<= 1;
-    p.tree_wide_threads = t;
-  } else {
-    while ((p.nseg / 2) / p.tree_parts > 4 * 64) p.tree_parts <<= 1;
-  }
-  p.partial_count = (size_t)p.W * (p.K + 2);
+  p.total_segs = (size_t)p.W * reduce_scratch_elems(lb);
+  p.partial_count = (size_t)p.W * (lb + 1);
   return p;
 }
 
@@ -373,17 +353,17 @@ Jacobian normalise(const Jacobian& p) {
   return r;
 }
 
-// Window value  W_w = partial[w][K] + partial[w][K+1] + 8 * sum_k 2^k * partial[w][k]  (sum T, sum S) and the final Horner
-// sum_w 2^(c*w) W_w, fused into ONE pass over bit positions: term partial[w][K] sits at bit c*w,
-// partial[w][k] at bit c*w + 3 + k.  Replaces sum_reduction_final + final_accumulation.rs:19-39.
+// Window value  W_w = partial[w][lb] + sum_k 2^k * partial[w][k]  (total; bit sums of the column sums for k < L, of the
+// row sums -- already offset by L -- for L <= k < lb; see k_reduce.hip) and the final Horner sum_w 2^(c*w) W_w, fused
+// into ONE pass over bit positions: term partial[w][k] sits at bit c*w + k, the total at bit c*w.
+// Replaces sum_reduction_final + final_accumulation.rs:19-39.
 Jacobian host_combine(const Jacobian* partial, const Plan& p) {
-  const uint32_t top = p.c * p.W;   // exclusive upper bound of bit positions
+  const uint32_t top = p.c * (p.W - 1) + p.lb;   // highest bit position in use
   std::vector<std::vector<const Jacobian*>> at(top + 1);
   for (uint32_t w = 0; w < p.W; ++w) {
-    const Jacobian* pw = partial + (size_t)w * (p.K + 2);
-    at[p.c * w].push_back(&pw[p.K]);
-    at[p.c * w].push_back(&pw[p.K + 1]);
-    for (uint32_t k = 0; k < p.K; ++k) at[p.c * w + kSegLog + k].push_back(&pw[k]);
+    const Jacobian* pw = partial + (size_t)w * (p.lb + 1);
+    at[p.c * w].push_back(&pw[p.lb]);
+    for (uint32_t k = 0; k < p.lb; ++k) at[p.c * w + k].push_back(&pw[k]);
   }
   Jacobian acc = jac_identity();
   for (int pos = (int)top; pos >= 0; --pos) {
@@ -497,7 +477,6 @@ int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, hipStream_t st, const Plan& p
   int rc;
   if ((rc = ensure(ctx, w.S, p.total_segs * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.T, p.total_segs * sizeof(PtI)))) return rc;
-  if ((rc = ensure(ctx, w.tree_tmp, p.partial_count * p.tree_parts * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.partial, p.partial_count * sizeof(Jacobian)))) return rc;
   launch_reduce(st, p, buckets, bucket_size, (PtI*)w.S.p, (PtI*)w.T.p, (PtI*)w.tree_tmp.p, (Jacobian*)w.partial.p);
   HIP_TRY(ctx, hipGetLastError());
@@ -1631,7 +1610,7 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   Plan one = p;
   one.W = 1;
   for (uint32_t w = 0; w < num_windows; ++w) {
-    const Jacobian r = host_combine(partial.data() + (size_t)w * (p.K + 2), one);
+    const Jacobian r = host_combine(partial.data() + (size_t)w * (p.lb + 1), one);
     jac_to_be32(r, res_out + (size_t)w * 24);
   }
   return MSM_AMD_OK;
