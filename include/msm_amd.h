@@ -101,7 +101,7 @@ const char* msm_amd_last_error(const msm_amd_ctx* ctx);
 int msm_amd_set_window_size(msm_amd_ctx* ctx, uint32_t window_size);
 /* The automatic choice for n points.  Reference policy: 3 if n < 32 else 15 (msm.rs:135-141).  This library: 3 below
  * 32 points, then the window measured fastest on MI355X per size class (5 up to 2^14 points, 13 up to 2^16, 15 up
- * to 2^19, 16 up to 2^21, 17 beyond); this function is the only source of truth -- results never depend on it. */
+ * to 2^18, 16 at 2^19, 17 beyond); this function is the only source of truth -- results never depend on it. */
 uint32_t msm_amd_auto_window_size(size_t n);
 
 /* ---- whole-MSM entry points: host buffers ---------------------------------------------------- */

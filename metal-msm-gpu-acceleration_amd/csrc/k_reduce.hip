@@ -137,7 +137,7 @@ size_t reduce_scratch_elems(uint32_t lb) {
 // partial[w][L .. L+H-1]    bit sums of the row sums    (weights 2^(L + k))
 // partial[w][lb]            sum of all buckets of the window (weight 1)
 void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, const uint32_t* bucket_size, PtI* S, PtI* T,
-                   PtI* /*tree_tmp*/, Jacobian* partial) {
+                   Jacobian* partial) {
   const uint32_t L = p.red_L, H = p.red_H;
   const uint32_t ncols = 1u << L, nrows = 1u << H;
   // family 0: row sums R[w][hi] (scratch S), family 1: column sums C[w][lo] (scratch T)

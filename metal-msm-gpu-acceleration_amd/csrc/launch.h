@@ -9,8 +9,7 @@
 
 namespace msm_amd {
 
-constexpr int kSegLog = 3;   // window reduction: segments of 2^3 buckets
-constexpr int kSeg = 1 << kSegLog;
+constexpr int kSegLog = 3;   // a window has at least 2^3 bucket slots (c = 3 is padded)
 
 // Geometry of one MSM (see make_plan in msm_host.hip).
 struct Plan {
@@ -80,8 +79,9 @@ int reduce_set_attributes(const char** failed);
 size_t reduce_scratch_elems(uint32_t lb);   // PtI elements of S and of T per window
 // bucket_size: [W][nb] point counts (zero = the bucket was never written and counts as the identity), or nullptr
 // when every bucket holds a valid point (stage entry point sum_reduction)
+// S, T: scratch of the row-sum / column-sum family, W * reduce_scratch_elems(lb) elements each
 void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, const uint32_t* bucket_size, PtI* S, PtI* T,
-                   PtI* tree_tmp, Jacobian* partial);
+                   Jacobian* partial);
 
 // k_misc.hip
 void launch_projective_to_affine(hipStream_t st, const Jacobian* in, uint32_t n, Affine* out);

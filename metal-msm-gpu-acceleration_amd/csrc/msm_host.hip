@@ -58,7 +58,7 @@ struct InstanceSlot {
 // 1024-thread sort workgroups of the other stream from being placed at all.)
 struct Workspace {
   DeviceBuf digits, coarse_cnt, region_start, tmp_idx, tmp_fine, tmp_idx2, tmp_fine2, mid_cnt, region_start2, bsize, bstart, istart, win_items, size_bins, sorted,
-      order, multi_list, counters, bases29, buckets, item_partials, S, T, tree_tmp, partial, conv_scalars, conv_points,
+      order, multi_list, counters, bases29, buckets, item_partials, S, T, partial, conv_scalars, conv_points,
       conv_tmp;
   hipEvent_t front_done = nullptr;    // front stream: sorted indices / work items of this workspace are ready
   hipEvent_t acc_done = nullptr;      // main stream: buckets of this workspace are complete (incl. combine)
@@ -184,17 +184,19 @@ uint32_t floor_log2(size_t n) {
 }
 
 uint32_t auto_window(size_t n) {
-  // The reference uses 3 below 32 points and 15 from there on (msm.rs:137-141).  Measured on MI355X in batches
-  // (ms per MSM): 2^12 c=5 0.23 | 2^14 c=5 0.24 | 2^16 c=13 0.33 | 2^17..2^19 c=15 0.38 / 0.51 / 0.90 |
-  // 2^20 c=16 1.55 (15: 1.59) | 2^21 c=16 3.20 | 2^22 c=17 6.47 | 2^23 c=17 12.9.  Windows whose TOP digit is
-  // narrow are traps: the n entries of the top window then share a handful of buckets (c = 14 leaves 2 bits for
-  // the top window of a 254-bit scalar, c = 11 one bit: 2^17 points cost 1.2 ms with c = 10 or 11, 0.38 with 15).
+  // The reference uses 3 below 32 points and 15 from there on (msm.rs:137-141).  Measured on MI355X in pipelined
+  // batches (ms per MSM, round 2 -- the row / column-sum reduction made buckets cheaper, which moved every
+  // boundary one size down): 2^12 c=5 0.23 | 2^14 c=5 0.24 | 2^16 c=13 0.33 | 2^18 c=15 0.47 (16: 0.50) |
+  // 2^19 c=16 0.79 (15: 0.80, 17: 0.84) | 2^20 c=17 1.41 (16: 1.43, 15: 1.54) | 2^21 c=17 2.72 (16: 2.83) |
+  // 2^22 c=17 5.82 (16: 6.21).  Windows whose TOP digit is narrow are traps: the n entries of the top window then
+  // share a handful of buckets (c = 14 leaves 2 bits for the top window of a 254-bit scalar, c = 11 one bit: 2^17
+  // points cost 1.2 ms with c = 10 or 11, 0.38 with 15).
   if (n < 32) return 3;   // msm.rs:137-138
   const uint32_t l = floor_log2(n);
   if (l <= 14) return 5;
   if (l <= 16) return 13;
-  if (l <= 19) return 15;
-  if (l <= 21) return 16;   // u32 digits from here on
+  if (l <= 18) return 15;
+  if (l == 19) return 16;   // u32 digits from here on
   return kMaxWindow;
 }
 
@@ -478,7 +480,7 @@ int enqueue_reduce(msm_amd_ctx* ctx, Workspace& w, hipStream_t st, const Plan& p
   if ((rc = ensure(ctx, w.S, p.total_segs * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.T, p.total_segs * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.partial, p.partial_count * sizeof(Jacobian)))) return rc;
-  launch_reduce(st, p, buckets, bucket_size, (PtI*)w.S.p, (PtI*)w.T.p, (PtI*)w.tree_tmp.p, (Jacobian*)w.partial.p);
+  launch_reduce(st, p, buckets, bucket_size, (PtI*)w.S.p, (PtI*)w.T.p, (Jacobian*)w.partial.p);
   HIP_TRY(ctx, hipGetLastError());
   return MSM_AMD_OK;
 }
@@ -948,7 +950,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     Workspace& w = ctx->ws[k];
     DeviceBuf* bufs[] = {&w.digits, &w.coarse_cnt, &w.region_start, &w.tmp_idx, &w.tmp_fine, &w.tmp_idx2, &w.tmp_fine2, &w.mid_cnt, &w.region_start2, &w.bsize, &w.bstart, &w.istart, &w.win_items, &w.size_bins, &w.sorted,
                          &w.order, &w.multi_list, &w.counters, &w.bases29, &w.buckets, &w.item_partials, &w.S, &w.T,
-                         &w.tree_tmp, &w.partial, &w.conv_scalars, &w.conv_points, &w.conv_tmp};
+                         &w.partial, &w.conv_scalars, &w.conv_points, &w.conv_tmp};
     for (DeviceBuf* b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (w.front_done) (void)hipEventDestroy(w.front_done);
