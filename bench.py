@@ -36,6 +36,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the drop-in-caller figures (host slices, lone calls)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
+    ap.add_argument("--depth", type=int, default=1, choices=[1, 2, 3],
+                    help="steps submitted ahead of the one being collected (submit/wait API, at most 4 batches in flight)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend of the result gather: nccl (= RCCL over xGMI, the measured configuration) "
                          "or gloo (rehearsal of the N-rank path on a box with fewer GPUs than ranks)")
@@ -153,17 +155,17 @@ def main(argv=None):
         cfg.synchronize()
 
     def run_steps(k, record):
-        """k steps, software-pipelined: step i+1 is submitted before step i is waited for, so the GPU never
-        idles between steps; every step's results are produced and returned inside the loop."""
-        outs, pending = None, None
+        """k steps, software-pipelined: up to `--depth` steps are submitted before the oldest one is waited for
+        (the library allows four batches in flight), so the GPU never idles between steps even when the host is
+        briefly late; every step's results are produced and returned inside the loop."""
+        outs, pending = None, []
         for _ in range(k):
-            h = cfg.submit_batch_device(d_sc, d_pts, ns, point_layout=point_layout)
-            if pending is not None:
-                outs, t = finish(pending)
+            pending.append(cfg.submit_batch_device(d_sc, d_pts, ns, point_layout=point_layout))
+            if len(pending) > args.depth:
+                outs, t = finish(pending.pop(0))
                 record(t)
-            pending = h
-        if pending is not None:
-            outs, t = finish(pending)
+        while pending:
+            outs, t = finish(pending.pop(0))
             record(t)
         return outs
 
@@ -312,7 +314,8 @@ def main(argv=None):
                                       + ("RCCL all_gather of 96-byte results" if args.backend == "nccl" else
                                          "gloo all_gather of 96-byte results (REHEARSAL"
                                          + (", ranks share a GPU: not a scaling measurement)" if shared else ")")),
-                       "pipelining": "step k+1 is submitted before step k's results are collected (submit/wait API)",
+                       "pipelining": f"{args.depth} step(s) are submitted ahead of the one whose results are being "
+                                     f"collected (submit/wait API)",
                        "bases": "precomputed window tables (built once, NOT the headline configuration)"
                                 if args.precomputed_tables else
                                 "persistent (converted once, NOT the headline configuration)"
