@@ -327,10 +327,35 @@ struct Field {
 
   MSM_HD static u256 to_mont(const u256& a) { return mul(a, r2()); }
 
+  // a * R^-1 mod p: the Montgomery reduction alone (64 limb products instead of the 128 of mul(a, 1)); the
+  // de-Montgomery of every scalar in digits_kernel.
   MSM_HD static u256 from_mont(const u256& a) {
+#if !defined(__HIP_DEVICE_COMPILE__)
     u256 o = u256_zero();
     o.v[0] = 1;
     return mul(a, o);
+#else
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    uint32_t m[8];
+    u256 r;
+    MSM_UNROLL for (int k = 0; k < 8; ++k) {
+      mac96(lo, hi, a.v[k], 1u);
+      MSM_UNROLL for (int i = 0; i < k; ++i) mac96_k(lo, hi, m[i], F::mod(k - i));
+      m[k] = (uint32_t)lo * F::INV;
+      mac96_k(lo, hi, m[k], F::mod(0));
+      lo = (lo >> 32) | ((uint64_t)hi << 32);
+      hi = 0;
+    }
+    MSM_UNROLL for (int k = 8; k < 15; ++k) {
+      MSM_UNROLL for (int i = k - 7; i < 8; ++i) mac96_k(lo, hi, m[i], F::mod(k - i));
+      r.v[k - 8] = (uint32_t)lo;
+      lo = (lo >> 32) | ((uint64_t)hi << 32);
+      hi = 0;
+    }
+    r.v[7] = (uint32_t)lo;
+    return reduce_once(r);
+#endif
   }
 
   // a^e for a 32-bit exponent (fp_bn254.h.metal `pow`), square-and-multiply MSB first.
