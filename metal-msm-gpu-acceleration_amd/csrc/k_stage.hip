@@ -265,15 +265,21 @@ void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_
   hipLaunchKernelGGL(pad_buckets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, bs, W, lb, out);
 }
 
-// block_counts: ceil(n / 1024) + 1 words; after the call block_counts[nblocks] holds the number of survivors.
-void launch_filter_zeros(hipStream_t st, const u256* scalars, const Affine* points, uint32_t n, uint32_t* block_counts,
-                         u256* out_scalars, Affine* out_points) {
+// Two steps, so that the caller can skip the compaction when too few scalars are zero (msm.rs:470: 30 %).
+// block_counts: ceil(n / 1024) + 1 words; after launch_filter_count block_counts[nblocks] holds the number of
+// survivors and block_counts[b] the first output position of block b.
+void launch_filter_count(hipStream_t st, const u256* scalars, uint32_t n, uint32_t* block_counts) {
   const uint32_t nblocks = (n + kFilterThreads - 1) / kFilterThreads;
   hipLaunchKernelGGL(filter_count_kernel, dim3(nblocks), dim3(kFilterThreads), 0, st, scalars, n, block_counts);
   (void)hipMemsetAsync(block_counts + nblocks, 0, 4, st);
   hipLaunchKernelGGL(linear_scan_kernel, dim3(1), dim3(1024), 0, st, block_counts, (size_t)nblocks + 1);
-  hipLaunchKernelGGL(filter_scatter_kernel, dim3(nblocks), dim3(kFilterThreads), 0, st, scalars, points, n,
-                     (const uint32_t*)block_counts, out_scalars, out_points);
+}
+
+void launch_filter_scatter(hipStream_t st, const u256* scalars, const Affine* points, uint32_t n,
+                           const uint32_t* block_counts, u256* out_scalars, Affine* out_points) {
+  const uint32_t nblocks = (n + kFilterThreads - 1) / kFilterThreads;
+  hipLaunchKernelGGL(filter_scatter_kernel, dim3(nblocks), dim3(kFilterThreads), 0, st, scalars, points, n, block_counts,
+                     out_scalars, out_points);
 }
 
 void launch_test_op(hipStream_t st, int op, const u256* a, const u256* b, u256* out, uint32_t count) {

@@ -102,8 +102,9 @@ void launch_radix_sort_pairs(hipStream_t st, uint2* a, uint2* b, size_t n, uint3
 void launch_ref_accumulate(hipStream_t st, const uint2* pairs, size_t n_pairs, const Jacobian* points,
                            uint32_t n_points, uint32_t total_buckets, Jacobian* buckets);
 void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t lb, PtI* out);
-void launch_filter_zeros(hipStream_t st, const u256* scalars, const Affine* points, uint32_t n, uint32_t* block_counts,
-                         u256* out_scalars, Affine* out_points);
+void launch_filter_count(hipStream_t st, const u256* scalars, uint32_t n, uint32_t* block_counts);
+void launch_filter_scatter(hipStream_t st, const u256* scalars, const Affine* points, uint32_t n,
+                           const uint32_t* block_counts, u256* out_scalars, Affine* out_points);
 void launch_test_op(hipStream_t st, int op, const u256* a, const u256* b, u256* out, uint32_t count);
 
 // host_msm.hip (host code only)

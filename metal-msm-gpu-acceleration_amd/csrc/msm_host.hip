@@ -1158,28 +1158,28 @@ int msm_amd_msm_best(msm_amd_ctx* ctx, const void* scalars, const void* points, 
   const uint32_t nblocks = (uint32_t)((n + 1023) / 1024);
   if ((rc = ensure(ctx, ctx->scratch_b, n * 32))) return rc;
   if ((rc = ensure(ctx, ctx->scratch_c, n * 64))) return rc;
-  if ((rc = ensure(ctx, ctx->scratch_a, ((size_t)nblocks + 1) * 4 + n * 96))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars, n * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, points, n * 64, hipMemcpyHostToDevice, st));
-  // filter_zeros (msm.rs:448-507): compact on the device, keep the compaction only if >= 30 % were zero
+  // filter_zeros (msm.rs:448-507): count the zero scalars on the device as soon as the scalars have arrived (the
+  // points upload runs behind it), compact only if >= 30 % were zero (msm.rs:470)
+  if ((rc = ensure(ctx, ctx->scratch_a, (((size_t)nblocks + 1) * 4 + 63) / 64 * 64 + n * 96))) return rc;
   uint32_t* counts = (uint32_t*)ctx->scratch_a.p;
   u256* f_sc = (u256*)((uint8_t*)ctx->scratch_a.p + (((size_t)nblocks + 1) * 4 + 63) / 64 * 64);
   Affine* f_pt = (Affine*)(f_sc + n);
-  if ((rc = ensure(ctx, ctx->scratch_a, (((size_t)nblocks + 1) * 4 + 63) / 64 * 64 + n * 96))) return rc;
-  counts = (uint32_t*)ctx->scratch_a.p;
-  f_sc = (u256*)((uint8_t*)ctx->scratch_a.p + (((size_t)nblocks + 1) * 4 + 63) / 64 * 64);
-  f_pt = (Affine*)(f_sc + n);
-  launch_filter_zeros(st, (const u256*)ctx->scratch_b.p, (const Affine*)ctx->scratch_c.p, (uint32_t)n, counts, f_sc,
-                      f_pt);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars, n * 32, hipMemcpyHostToDevice, st));
+  launch_filter_count(st, (const u256*)ctx->scratch_b.p, (uint32_t)n, counts);
   HIP_TRY(ctx, hipGetLastError());
   uint32_t survivors = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&survivors, counts + nblocks, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, points, n * 64, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   const double zero_ratio = (double)(n - survivors) / (double)n;
   const void* ds = ctx->scratch_b.p;
   const void* dp = ctx->scratch_c.p;
   size_t m = n;
   if (zero_ratio >= 0.30) {   // msm.rs:470
+    launch_filter_scatter(st, (const u256*)ctx->scratch_b.p, (const Affine*)ctx->scratch_c.p, (uint32_t)n, counts, f_sc,
+                          f_pt);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));   // run_batch_device starts on the front stream
     ds = f_sc;
     dp = f_pt;
     m = survivors;
