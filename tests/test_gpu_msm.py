@@ -327,3 +327,18 @@ def test_canonical_scalars_at_or_above_r_are_reduced(cfg, msm_pkg, c):
     finally:
         cfg.set_window_size(0)
     assert o.decode_jacobian_mont_le(out) == o.msm_naive([k % o.R_ORDER for k in raw], pts)
+
+
+def test_ragged_host_batch_more_instances_than_tickets(cfg, msm_pkg):
+    """msm_amd_msm_batch with seven instances of very different sizes: more instances than batch tickets (4) and than
+    instances in flight (3), two staging sets sized by the largest instance, every result against the oracle."""
+    from oracle import c_oracle as co
+    sizes = [1000, 17, 4096, 3, 70000, 256, 1]
+    data = [co.gen_instance(o.SEED_BASE + 600 + j, n) for j, n in enumerate(sizes)]
+    pts, scs = [d[0] for d in data], [d[1] for d in data]
+    outs = cfg.msm_batch(scs, pts, sizes)
+    assert len(outs) == len(sizes)
+    for j, n in enumerate(sizes):
+        assert o.decode_jacobian_mont_le(outs[j]) == o.decode_jacobian_mont_le(co.msm_best(scs[j], pts[j], n, 2)), j
+    # the same instances one by one give the same bytes
+    assert [msm_pkg.gpu_msm_h2c(scs[j], pts[j], cfg) for j in range(len(sizes))] == outs
