@@ -96,6 +96,12 @@ def main(argv=None):
         os.environ.setdefault("MASTER_PORT", str(mg.free_port()))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
+    # stdout carries exactly ONE line, the result: everything libraries print while the run is set up and timed (the
+    # RCCL banner at communicator creation, for one) goes to stderr; the descriptor is restored for the JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     visible = torch.cuda.device_count()     # does not initialise the GPU
@@ -330,7 +336,10 @@ def main(argv=None):
             "cpu_baseline": cpu,
             "drop_in_caller": extras,
         }
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     for j in range(inst):
         if tables:
             cfg.tables_free(d_pts[j])
