@@ -101,6 +101,7 @@ struct msm_amd_ctx {
   std::vector<std::pair<const void*, size_t>> host_regs;   // msm_amd_host_register
   bool overlap_reduce = true;            // MSM_AMD_OVERLAP_REDUCE=0 puts the reduction on the main stream
   bool overlap_front = true;             // MSM_AMD_OVERLAP_FRONT=0 puts the front end on the main stream
+  bool lone_single_stream = true;        // MSM_AMD_LONE_SINGLE_STREAM=0: a lone instance uses the stream split too
   Workspace ws[kWorkspaces];
   std::mutex mu;
   std::string last_error;
@@ -397,6 +398,20 @@ int slot_prepare(msm_amd_ctx* ctx, InstanceSlot& s, size_t partial_count) {
   return MSM_AMD_OK;
 }
 
+// ONE instance submitted while nothing else is in flight (what a blocking gpu_msm_h2c call is) runs on ONE stream:
+// the front / accumulate / reduce split exists to overlap neighbouring instances, and with no neighbour its three
+// cross-stream event hand-offs are pure latency -- 29 + 28 + 18 us of GPU idle time inside a 742 us call at 2^18
+// points (profiles/r02_lone_call_2p18_timeline.txt).
+bool lone_call(const msm_amd_ctx* ctx, size_t n_inst) {
+  if (n_inst != 1 || !ctx->lone_single_stream) return false;
+  for (const Batch& b : ctx->batches)
+    if (b.active) return false;
+  return true;
+}
+hipStream_t front_stream_of(const msm_amd_ctx* ctx, bool lone) {
+  return (lone || !ctx->overlap_front) ? ctx->stream : ctx->front_stream;
+}
+
 // Bring inputs to the native device layout (affine 64 B Montgomery LE; scalars 32 B LE).
 // On return *scalars_native / *points_native point to device memory valid until the next call.
 int convert_inputs(msm_amd_ctx* ctx, Workspace& w, hipStream_t st, int scalar_layout, int point_layout, const void* d_scalars,
@@ -493,7 +508,7 @@ const msm_amd_tables* find_tables(const msm_amd_ctx* ctx, const void* handle) {
 
 // Enqueue one whole MSM on the ctx stream; results land in slot.h_partial after slot.ev[EV_REDUCE].
 int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_layout, int point_layout, const void* d_scalars,
-                const void* d_points, size_t n, Plan* plan_out) {
+                const void* d_points, size_t n, Plan* plan_out, bool lone) {
   hipStream_t st = ctx->stream;
   const msm_amd_tables* tb = nullptr;
   if (point_layout == MSM_AMD_POINT_TABLES) {   // d_points is the handle of msm_amd_tables_build*
@@ -558,13 +573,15 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   //            accumulate and reduction done; runs while instance i-1 accumulates and i-2 reduces
   //   main   : accumulate of instance i                                      -- needs front(i)
   //   reduce : combine + window reduction + copy of instance i               -- needs main(i)
-  hipStream_t fs = ctx->overlap_front ? ctx->front_stream : st;
-  hipStream_t rs = ctx->overlap_reduce ? ((ctx->alt_reduce && (ctx->seq++ & 1u)) ? ctx->reduce_stream2 : ctx->reduce_stream) : st;
-  if (w.acc_pending && fs != st) {   // the previous accumulate in this workspace still reads its plan ...
+  hipStream_t fs = front_stream_of(ctx, lone);
+  hipStream_t rs = (lone || !ctx->overlap_reduce)
+                       ? st
+                       : ((ctx->alt_reduce && (ctx->seq++ & 1u)) ? ctx->reduce_stream2 : ctx->reduce_stream);
+  if (w.acc_pending && (fs != st || lone)) {   // the previous accumulate in this workspace still reads its plan ...
     HIP_TRY(ctx, hipStreamWaitEvent(fs, w.acc_done, 0));
   }
-  if (w.reduce_pending && fs != rs) {   // ... and so does its combine pass on the reduce stream
-    HIP_TRY(ctx, hipStreamWaitEvent(fs, w.reduce_done, 0));
+  if (w.reduce_pending && (fs != rs || lone)) {   // ... and so does its combine pass (on whichever reduce stream
+    HIP_TRY(ctx, hipStreamWaitEvent(fs, w.reduce_done, 0));   // the previous user of the workspace had)
   }
   w.acc_pending = false;
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_START], fs));
@@ -658,9 +675,11 @@ void accumulate_timings(msm_amd_ctx* ctx, InstanceSlot& s, const Plan& p, float 
 //   submit_batch_device  enqueues every kernel of every instance (three streams, see enqueue_msm) and returns
 //   wait_batch           finishes each instance on the host as soon as its partial points have landed (the host
 //                        Horner pass of instance i overlaps the GPU work of i+1.. and of later batches)
+// lone_hint: -1 = decide here (one instance, nothing in flight), 0 / 1 = the caller (run_batch_host, which submits
+// the instances of ITS batch one by one and has already put the upload waits on a stream) decided
 int submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
                         const void* const* d_scalars, const void* const* d_points, const size_t* n, void* out_host,
-                        int* ticket) {
+                        int* ticket, int lone_hint = -1) {
   if (!ctx || !d_scalars || !d_points || !n || !out_host || !ticket || n_inst == 0)
     return fail(ctx, MSM_AMD_INPUT_ERROR, "null argument or empty batch");
   if (point_bytes(point_layout) == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown point layout");
@@ -676,6 +695,7 @@ int submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, s
     }
   if (id < 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "too many batches in flight: wait for one first");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const bool lone = lone_hint < 0 ? lone_call(ctx, n_inst) : lone_hint != 0;
   Batch& B = ctx->batches[id];
   if (B.slots.size() < n_inst) B.slots.resize(n_inst);
   B.plans.assign(n_inst, Plan{});
@@ -684,7 +704,8 @@ int submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, s
   for (size_t i = 0; i < n_inst; ++i) {
     Workspace& w = ctx->ws[ctx->next_ws];
     ctx->next_ws = (ctx->next_ws + 1) % kWorkspaces;
-    int rc = enqueue_msm(ctx, w, B.slots[i], scalar_layout, point_layout, d_scalars[i], d_points[i], n[i], &B.plans[i]);
+    int rc = enqueue_msm(ctx, w, B.slots[i], scalar_layout, point_layout, d_scalars[i], d_points[i], n[i], &B.plans[i],
+                         lone);
     if (rc) {   // nothing of a failed submit stays in flight; the batch slot was never marked active
       drain_streams(ctx);
       return rc;
@@ -796,7 +817,8 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
       for (DeviceBuf* b : {&ctx->scratch_c, &ctx->scratch_c2})
         if ((rc = ensure(ctx, *b, max_n * pb))) return rc;
   }
-  hipStream_t fs = ctx->overlap_front ? ctx->front_stream : ctx->stream;
+  const bool lone = lone_call(ctx, n_inst);
+  hipStream_t fs = front_stream_of(ctx, lone);
   for (size_t i = 0; i < n_inst; ++i) {
     int rc;
     if (i >= kInflight && (rc = collect(i - kInflight))) return bail(rc);
@@ -816,7 +838,8 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
     const void* ds = sbuf.p;
     const void* dp = dev_points ? points[i] : pbuf.p;
     int ticket = -1;
-    rc = submit_batch_device(ctx, scalar_layout, point_layout, 1, &ds, &dp, &n[i], (uint8_t*)out + i * 96, &ticket);
+    rc = submit_batch_device(ctx, scalar_layout, point_layout, 1, &ds, &dp, &n[i], (uint8_t*)out + i * 96, &ticket,
+                             lone ? 1 : 0);
     if (rc) return bail(rc);
     tickets[i] = ticket;
   }
@@ -878,6 +901,7 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   if (const char* e = std::getenv("MSM_AMD_OVERLAP_REDUCE")) ctx->overlap_reduce = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSM_AMD_OVERLAP_FRONT")) ctx->overlap_front = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSM_AMD_ALT_REDUCE")) ctx->alt_reduce = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MSM_AMD_LONE_SINGLE_STREAM")) ctx->lone_single_stream = std::atoi(e) != 0;
   ctx->low_occ_accumulate = ctx->overlap_front;
   if (const char* e = std::getenv("MSM_AMD_LOW_OCC")) ctx->low_occ_accumulate = std::atoi(e) != 0;
   int prio_least = 0, prio_greatest = 0;
@@ -1052,7 +1076,7 @@ int msm_amd_gpu_msm_h2c_sync(msm_amd_ctx* ctx, const void* scalars, const void* 
   int rc;
   if ((rc = ensure(ctx, ctx->scratch_b, n * 32))) return rc;
   if ((rc = ensure(ctx, ctx->scratch_c, n * 64))) return rc;
-  hipStream_t up = ctx->overlap_front ? ctx->front_stream : ctx->stream;
+  hipStream_t up = front_stream_of(ctx, lone_call(ctx, 1));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars, n * 32, hipMemcpyHostToDevice, up));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, points, n * 64, hipMemcpyHostToDevice, up));
   const void* ds = ctx->scratch_b.p;
@@ -1389,7 +1413,7 @@ int msm_amd_msm_tables(msm_amd_ctx* ctx, const msm_amd_tables* tables, int scala
   int rc;
   const size_t n = t->n;
   if ((rc = ensure(ctx, ctx->scratch_b, n * 32))) return rc;
-  hipStream_t up = ctx->overlap_front ? ctx->front_stream : ctx->stream;
+  hipStream_t up = front_stream_of(ctx, lone_call(ctx, 1));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars, n * 32, hipMemcpyHostToDevice, up));
   const void* ds = ctx->scratch_b.p;
   const void* dp = tables;
@@ -1406,7 +1430,7 @@ int msm_amd_msm_prepared(msm_amd_ctx* ctx, int scalar_layout, const void* scalar
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = ensure(ctx, ctx->scratch_b, n * 32))) return rc;
-  hipStream_t up = ctx->overlap_front ? ctx->front_stream : ctx->stream;
+  hipStream_t up = front_stream_of(ctx, lone_call(ctx, 1));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_b.p, scalars, n * 32, hipMemcpyHostToDevice, up));
   const void* ds = ctx->scratch_b.p;
   return run_batch_device(ctx, scalar_layout, MSM_AMD_POINT_PREPARED, 1, &ds, &d_prepared, &n, out96);

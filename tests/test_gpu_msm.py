@@ -342,3 +342,26 @@ def test_ragged_host_batch_more_instances_than_tickets(cfg, msm_pkg):
         assert o.decode_jacobian_mont_le(outs[j]) == o.decode_jacobian_mont_le(co.msm_best(scs[j], pts[j], n, 2)), j
     # the same instances one by one give the same bytes
     assert [msm_pkg.gpu_msm_h2c(scs[j], pts[j], cfg) for j in range(len(sizes))] == outs
+
+
+def test_lone_single_stream_call_mixed_with_pipelined_batches(cfg, msm_pkg):
+    """A single instance submitted while nothing is in flight runs on ONE stream (no cross-stream hand-offs); batches
+    submitted right behind it use the stream split and share the workspaces' events with it.  Same bytes as blocking
+    calls, in any interleaving."""
+    n = 5000
+    insts = [cfg.generate_instance(o.SEED_BASE + 700 + j, n, True) for j in range(5)]
+    dp = [i[0] for i in insts]
+    ds = [i[1] for i in insts]
+    try:
+        want = [cfg.msm_batch_device([ds[j]], [dp[j]], [n])[0] for j in range(5)]     # five lone calls
+        for _ in range(3):
+            h0 = cfg.submit_batch_device([ds[0]], [dp[0]], [n])                      # lone: single stream
+            h1 = cfg.submit_batch_device(ds[1:4], dp[1:4], [n] * 3)                  # behind it: pipelined
+            h2 = cfg.submit_batch_device([ds[4]], [dp[4]], [n])                      # one instance, but NOT lone
+            assert cfg.wait_batch(h1) == want[1:4]
+            assert cfg.wait_batch(h0) == [want[0]]
+            assert cfg.wait_batch(h2) == [want[4]]
+            assert cfg.msm_batch_device([ds[2]], [dp[2]], [n]) == [want[2]]         # lone again
+    finally:
+        for p in dp + ds:
+            cfg.free(p)
