@@ -3,6 +3,7 @@ deterministic generator, and the committed golden fixtures."""
 import json
 import os
 import random
+import pytest
 
 from oracle import bn254_ref as o
 from oracle import c_oracle as co
@@ -136,3 +137,45 @@ def test_golden_fixtures_match_oracle():
     for v in g["mul"]:
         a, b = int(v["a"], 16), int(v["b"], 16)
         assert hex(a * b % o.P) == v["ab"] and hex(o.mont_mul_p(o.fq_to_mont(a), o.fq_to_mont(b))) == v["mont_ab"]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 31, 32, 33, 200, 1500])
+def test_window_parallel_batched_affine_restatement(n):
+    """oracle_msm_best (halo2curves 0.7 msm_best shape: window tasks, Booth digits, affine buckets with batched
+    additions, Jacobian side buckets for collisions) against the definition (double-and-add) and against the second,
+    independent C implementation (oracle_msm_chunked), for every task layout: the halo2curves shape (groups = 1),
+    automatic groups, more groups than useful, one thread."""
+    from oracle import c_oracle as co
+    pts, sc = co.gen_instance(o.SEED_BASE + 3000 + n, n)
+    want = o.decode_jacobian_mont_le(co.msm_naive(sc, pts, n)) if n <= 200 else None
+    ref = o.decode_jacobian_mont_le(co.msm_chunked(sc, pts, n, 3))
+    if want is not None:
+        assert ref == want
+    for threads, groups in ((1, 1), (4, 1), (4, 0), (8, 5)):
+        got, info = co.msm_best_ex(sc, pts, n, threads, groups)
+        assert o.decode_jacobian_mont_le(got) == ref, (threads, groups, info)
+        assert info["threads_used"] >= 1 and info["windows"] >= 1
+
+
+def test_batched_affine_corner_cases():
+    """Equal points in one bucket (doubling inside a batch), P and -P (bucket becomes empty), identity bases, zero
+    scalars, and many hits on one bucket within a batch of 64 (the Jacobian side bucket)."""
+    from oracle import c_oracle as co
+    rng = random.Random(77)
+    n = 300
+    P = [o.scalar_mul(rng.randrange(1, o.R_ORDER), o.GEN) for _ in range(6)]
+    pts = [P[i % 6] for i in range(n)]
+    sc = [rng.randrange(o.R_ORDER) for _ in range(n)]
+    for i in range(0, 60):
+        sc[i] = 12345                      # the same digit pattern: one bucket per window gets 60 hits in a row
+    pts[70] = o.aff_neg(pts[64])
+    sc[70] = sc[64]                        # P + (-P) in the same bucket
+    pts[80] = None                         # identity base
+    sc[90] = 0
+    sb = b"".join(o.encode_scalar_h2c(k) for k in sc)
+    pb = b"".join(o.encode_affine_h2c(p) for p in pts)
+    want = o.msm_naive(sc, pts)
+    for threads, groups in ((1, 1), (4, 0), (3, 2)):
+        got, _ = co.msm_best_ex(sb, pb, n, threads, groups)
+        assert o.decode_jacobian_mont_le(got) == want
+    assert o.decode_jacobian_mont_le(co.msm_chunked(sb, pb, n, 2)) == want
