@@ -317,8 +317,15 @@ enum {
   MSM_AMD_OP_EC29_ADD = 23,        /* Jacobian a + Jacobian b on internal limbs */
   MSM_AMD_OP_EC29_MADD_CHAIN = 24, /* a + 64 b: 64 chained mixed additions kept in the lazy internal form */
   MSM_AMD_OP_EC29_ADD_CHAIN = 25,  /* a + 16 b: 16 chained full additions */
-  MSM_AMD_OP_EC29_MMADD = 26       /* -a - 4b: affine + affine (4M + 2S start of a work item) on lazily negated
+  MSM_AMD_OP_EC29_MMADD = 26,      /* -a - 4b: affine + affine (4M + 2S start of a work item) on lazily negated
                                       operands, then three mixed additions; a, b finite with z = one */
+  /* host only (msm_amd_test_op_host; msm_amd_test_op rejects them): the 4 x 64-bit arithmetic of the CPU tail of
+     every MSM -- window Horner pass and normalisation (csrc/host_fq64.h) */
+  MSM_AMD_OP_H64_FP_MUL = 27,
+  MSM_AMD_OP_H64_FP_ADD = 28,
+  MSM_AMD_OP_H64_FP_SUB = 29,
+  MSM_AMD_OP_H64_EC_ADD = 30,      /* Jacobian + Jacobian, 24 limbs each */
+  MSM_AMD_OP_H64_EC_DBL = 31
 };
 int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count);
 /* The same operation bodies executed on the host CPU (no GPU needed): host-logic tests. */

@@ -113,7 +113,6 @@ int reduce_set_attributes(const char** failed) {
   return 0;
 }
 
-constexpr uint32_t kGroup = 16;   // additions per lane and level: chains of 15, like the 8-slot running sums they replace
 
 // Elements of scratch one family (rows or columns) needs per window: all levels of the group sums.
 size_t reduce_scratch_elems(uint32_t lb) {
@@ -123,8 +122,8 @@ size_t reduce_scratch_elems(uint32_t lb) {
     const size_t rows = (size_t)1 << (fam ? L : H);
     uint32_t len = 1u << (fam ? H : L);
     size_t s = 0;
-    while (len > 1) {
-      len = (len + kGroup - 1) / kGroup;
+    while (len > 1) {   // the smallest group has the most levels and the most intermediate sums
+      len = (len + kReduceGroupMin - 1) / kReduceGroupMin;
       s += rows * len;
     }
     if (s == 0) s = rows;
@@ -140,6 +139,7 @@ void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, const uint
                    Jacobian* partial) {
   const uint32_t L = p.red_L, H = p.red_H;
   const uint32_t ncols = 1u << L, nrows = 1u << H;
+  const uint32_t min_group = std::min(std::max(p.red_group, kReduceGroupMin), kReduceGroup);
   // family 0: row sums R[w][hi] (scratch S), family 1: column sums C[w][lo] (scratch T)
   GroupJob job[2];
   PtI* next_dst[2] = {S, T};
@@ -155,10 +155,20 @@ void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, const uint
     J.len = fam ? nrows : ncols;
   }
   while (job[0].len > 1 || job[1].len > 1) {
+    // per level: the smallest group (shortest chains) whose outputs still fit the lanes one launch can have resident;
+    // red_group = kReduceGroup (pipelined instances) pins 16
+    uint32_t group = min_group;
+    while (group < kReduceGroup) {
+      size_t outs = 0;
+      for (int fam = 0; fam < 2; ++fam)
+        if (job[fam].len > 1) outs += (size_t)job[fam].total_rows * ((job[fam].len + group - 1) / group);
+      if (outs <= kReduceResidentLanes) break;
+      group <<= 1;
+    }
     for (int fam = 0; fam < 2; ++fam) {
       GroupJob& J = job[fam];
       if (J.len > 1) {
-        J.group = std::min(J.len, kGroup);
+        J.group = std::min(J.len, group);
         J.out_len = (J.len + J.group - 1) / J.group;
         J.outputs = J.total_rows * J.out_len;
         J.dst = next_dst[fam];

@@ -28,6 +28,7 @@ struct Plan {
   uint32_t front_threads;     // workgroup size of the sort / planning kernels (256..1024)
   uint32_t CH;                // accumulate: max points per work item (bucket chunk)
   uint32_t red_L, red_H;      // reduce: column / row bits of the slot index (L = ceil(lb / 2), H = lb - L)
+  uint32_t red_group;         // reduce: additions per lane and level of the row / column sums (kReduceGroupMin..16)
   size_t total_buckets, total_segs, partial_count, max_items;
 };
 
@@ -76,7 +77,10 @@ void launch_combine(hipStream_t st, const Plan& p, const SortBuffers& b, PtI* bu
 
 // k_reduce.hip
 int reduce_set_attributes(const char** failed);
-size_t reduce_scratch_elems(uint32_t lb);   // PtI elements of S and of T per window
+constexpr uint32_t kReduceGroup = 16;      // pipelined instances: chains of 15 additions, two levels at lb = 16
+constexpr uint32_t kReduceGroupMin = 4;    // a lone call trades launches for shorter chains (launch_reduce picks per level)
+constexpr size_t kReduceResidentLanes = 160 * 1024;   // sum_groups_kernel: <= 168 VGPRs, 3 waves/SIMD = 196 k lanes
+size_t reduce_scratch_elems(uint32_t lb);   // PtI elements of S and of T per window (sized for kReduceGroupMin)
 // bucket_size: [W][nb] point counts (zero = the bucket was never written and counts as the identity), or nullptr
 // when every bucket holds a valid point (stage entry point sum_reduction)
 // S, T: scratch of the row-sum / column-sum family, W * reduce_scratch_elems(lb) elements each

@@ -23,6 +23,7 @@
 #include "../../include/msm_amd.h"
 #include "device_common.hip.h"
 #include "launch.h"
+#include "host_fq64.h"
 #include "test_ops.hip.h"
 
 using namespace msm_amd;
@@ -39,7 +40,13 @@ struct DeviceBuf {
   size_t cap = 0;
 };
 
-enum { EV_START = 0, EV_CONVERT, EV_DIGITS, EV_SORT, EV_ACC_S, EV_ACC, EV_RED_S, EV_REDUCE, EV_ACC_K0, EV_ACC_K1, EV_COUNT };
+// One hipEventRecord costs ~6 us of stream idle time on this stack (profiles/r02_lone_call_2p18_timeline.txt: 5.7 us
+// between two kernels with one event between them, none without), so the accumulate kernel is bracketed by ONE pair
+// of events that serves as stage span, kernel span (the roofline figure of bench.py) and start of the reduce span.
+enum {
+  EV_START = 0, EV_CONVERT, EV_DIGITS, EV_SORT, EV_ACC_S, EV_ACC, EV_REDUCE, EV_COUNT,
+  EV_ACC_K0 = EV_ACC_S, EV_ACC_K1 = EV_ACC, EV_RED_S = EV_ACC
+};
 
 struct InstanceSlot {
   hipEvent_t ev[EV_COUNT];
@@ -301,6 +308,7 @@ Plan make_plan(size_t n_scalars, uint32_t c, uint32_t windows = 0) {
   p.CH = ch;
   p.red_L = (p.lb + 1) / 2;
   p.red_H = p.lb - p.red_L;
+  p.red_group = kReduceGroup;
   p.total_buckets = (size_t)p.W * p.nb;
   p.total_segs = (size_t)p.W * reduce_scratch_elems(p.lb);   // scratch elements of each of the two sum families
   p.max_items = p.total_buckets + ((size_t)p.W * n) / ch + 1;
@@ -317,6 +325,7 @@ Plan make_reduce_plan(uint32_t lb, uint32_t W) {
   p.nb = 1u << lb;
   p.red_L = (lb + 1) / 2;
   p.red_H = lb - p.red_L;
+  p.red_group = kReduceGroup;
   p.total_buckets = (size_t)p.W * p.nb;
   p.total_segs = (size_t)p.W * reduce_scratch_elems(lb);
   p.partial_count = (size_t)p.W * (lb + 1);
@@ -346,15 +355,7 @@ void jac_to_be32(const Jacobian& p, uint32_t* l) {
 }
 
 // Normalise to z = R mod p (or the canonical identity (1,1,0) in Montgomery form).
-Jacobian normalise(const Jacobian& p) {
-  Jacobian r;
-  if (jac_is_identity(p)) return jac_identity();
-  const Affine a = jac_to_affine(p);
-  r.x = a.x;
-  r.y = a.y;
-  r.z = Fq::one();
-  return r;
-}
+Jacobian normalise(const Jacobian& p) { return h64::store(h64::normalise(h64::load(p))); }
 
 // Window value  W_w = partial[w][lb] + sum_k 2^k * partial[w][k]  (total; bit sums of the column sums for k < L, of the
 // row sums -- already offset by L -- for L <= k < lb; see k_reduce.hip) and the final Horner sum_w 2^(c*w) W_w, fused
@@ -368,12 +369,13 @@ Jacobian host_combine(const Jacobian* partial, const Plan& p) {
     at[p.c * w].push_back(&pw[p.lb]);
     for (uint32_t k = 0; k < p.lb; ++k) at[p.c * w + k].push_back(&pw[k]);
   }
-  Jacobian acc = jac_identity();
+  // 4 x 64-bit host arithmetic (host_fq64.h): this pass is the whole CPU tail of an MSM
+  h64::Jac acc = h64::identity();
   for (int pos = (int)top; pos >= 0; --pos) {
-    acc = jac_double(acc);
-    for (const Jacobian* t : at[pos]) acc = jac_add(acc, *t);
+    acc = h64::jdouble(acc);
+    for (const Jacobian* t : at[pos]) acc = h64::jadd(acc, h64::load(*t));
   }
-  return acc;
+  return h64::store(acc);
 }
 
 int set_kernel_attributes(msm_amd_ctx* ctx) {
@@ -506,6 +508,16 @@ const msm_amd_tables* find_tables(const msm_amd_ctx* ctx, const void* handle) {
   return nullptr;
 }
 
+// Row / column sums of the window reduction for a LONE call: with no neighbouring instance to fill the machine, the
+// 15-addition chains of the pipelined setting (one lane per 16 buckets: 35 k lanes at 2^18 points, 7.7 k in the second
+// level at 2^20) are pure latency.  launch_reduce then takes, level by level, the smallest group (>= this minimum) whose
+// outputs still fit the lanes one launch can have resident; a further level costs one launch (~5 us), one addition
+// in a chain about 6 us.
+uint32_t pick_reduce_group(const Plan&) {
+  if (const char* e = std::getenv("MSM_AMD_REDUCE_GROUP")) return (uint32_t)std::atoi(e);
+  return kReduceGroupMin;
+}
+
 // Enqueue one whole MSM on the ctx stream; results land in slot.h_partial after slot.ev[EV_REDUCE].
 int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_layout, int point_layout, const void* d_scalars,
                 const void* d_points, size_t n, Plan* plan_out, bool lone) {
@@ -517,7 +529,8 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
     if (n != tb->n) return fail(ctx, MSM_AMD_INPUT_ERROR, "n differs from the number of points the tables hold");
   }
   const uint32_t c = tb ? tb->c : (ctx->forced_window ? ctx->forced_window : auto_window(n));
-  const Plan p = tb ? make_plan(n, c, tb->W) : make_plan(n, c);
+  Plan p = tb ? make_plan(n, c, tb->W) : make_plan(n, c);
+  if (lone) p.red_group = pick_reduce_group(p);
   *plan_out = p;
   int rc;
   if ((rc = slot_prepare(ctx, slot, p.partial_count))) return rc;
@@ -610,10 +623,8 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
     if (rs != st) HIP_TRY(ctx, hipStreamWaitEvent(st, w.reduce_done, 0));
     w.reduce_pending = false;
   }
-  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC_S], st));
   launch_accumulate(st, p, bases, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p,
                     ctx->low_occ_accumulate, slot.ev[EV_ACC_K0], slot.ev[EV_ACC_K1]);
-  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_ACC], st));
   HIP_TRY(ctx, hipEventRecord(w.acc_done, st));
   w.acc_pending = true;
 
@@ -621,7 +632,6 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   // accumulate.  front(i+2) reuses this workspace's plan buffers, which combine still reads: it waits for
   // reduce_done as well (see the top of this function).
   if (rs != st) HIP_TRY(ctx, hipStreamWaitEvent(rs, w.acc_done, 0));
-  HIP_TRY(ctx, hipEventRecord(slot.ev[EV_RED_S], rs));
   launch_combine(rs, p, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p);
   if ((rc = enqueue_reduce(ctx, w, rs, p, (const PtI*)w.buckets.p, (const uint32_t*)w.bsize.p))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(slot.h_partial, w.partial.p, p.partial_count * sizeof(Jacobian),
@@ -1644,13 +1654,13 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
 
 int msm_amd_sum_points(const void* points96, size_t count, void* out96) {
   if ((!points96 && count) || !out96) return MSM_AMD_INPUT_ERROR;
-  Jacobian acc = jac_identity();
+  h64::Jac acc = h64::identity();
   for (size_t i = 0; i < count; ++i) {
-    Jacobian p;
+    h64::Jac p;
     std::memcpy(&p, (const uint8_t*)points96 + i * 96, 96);
-    acc = jac_add(acc, p);
+    acc = h64::jadd(acc, p);
   }
-  const Jacobian res = normalise(acc);
+  const h64::Jac res = h64::normalise(acc);
   std::memcpy(out96, &res, 96);
   return MSM_AMD_OK;
 }
@@ -1658,12 +1668,12 @@ int msm_amd_sum_points(const void* points96, size_t count, void* out96) {
 int msm_amd_final_accumulation(const uint32_t* res_be32, uint32_t num_windows, uint32_t window_size,
                                uint32_t* point_out) {
   if (!res_be32 || !point_out || num_windows == 0) return MSM_AMD_INPUT_ERROR;
-  Jacobian acc = jac_identity();
+  h64::Jac acc = h64::identity();   // same formulas as jac_double / jac_add: identical coordinates, not only the same point
   for (int w = (int)num_windows - 1; w >= 0; --w) {
-    for (uint32_t i = 0; i < window_size; ++i) acc = jac_double(acc);
-    acc = jac_add(acc, be32_to_jac(res_be32 + (size_t)w * 24));
+    for (uint32_t i = 0; i < window_size; ++i) acc = h64::jdouble(acc);
+    acc = h64::jadd(acc, h64::load(be32_to_jac(res_be32 + (size_t)w * 24)));
   }
-  jac_to_be32(acc, point_out);
+  jac_to_be32(h64::store(acc), point_out);
   return MSM_AMD_OK;
 }
 
@@ -1704,8 +1714,32 @@ int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t*
   return MSM_AMD_OK;
 }
 
+// ops 27..31 exist on the host only: the 4 x 64-bit arithmetic of the CPU tail (host_fq64.h)
+static bool host64_test_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count) {
+  if (op < MSM_AMD_OP_H64_FP_MUL || op > MSM_AMD_OP_H64_EC_DBL) return false;
+  const bool pt = op >= MSM_AMD_OP_H64_EC_ADD;
+  for (size_t t = 0; t < count; ++t) {
+    if (!pt) {
+      const u256 xa = be32_to_u256(a + t * 8), xb = be32_to_u256(b + t * 8);
+      h64::Fe x, y, r;
+      std::memcpy(&x, &xa, 32);
+      std::memcpy(&y, &xb, 32);
+      r = op == MSM_AMD_OP_H64_FP_MUL ? h64::mul(x, y) : (op == MSM_AMD_OP_H64_FP_ADD ? h64::add(x, y) : h64::sub(x, y));
+      u256 ro;
+      std::memcpy(&ro, &r, 32);
+      u256_to_be32(ro, out + t * 8);
+    } else {
+      const h64::Jac p = h64::load(be32_to_jac(a + t * 24)), q = h64::load(be32_to_jac(b + t * 24));
+      jac_to_be32(h64::store(op == MSM_AMD_OP_H64_EC_ADD ? h64::jadd(p, q) : h64::jdouble(p)), out + t * 24);
+    }
+  }
+  return true;
+}
+
 int msm_amd_test_op_host(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count) {
-  if (!a || !b || !out || count == 0 || op < 0 || op > kTestOpMax) return MSM_AMD_INPUT_ERROR;
+  if (!a || !b || !out || count == 0 || op < 0) return MSM_AMD_INPUT_ERROR;
+  if (host64_test_op(op, a, b, out, count)) return MSM_AMD_OK;
+  if (op > kTestOpMax) return MSM_AMD_INPUT_ERROR;
   size_t wa, wb;
   test_op_widths(op, &wa, &wb);
   const size_t wo = wa;

@@ -294,3 +294,41 @@ def test_log22_three_level_sort_uniform_and_skewed(cfg):
     finally:
         cfg.free(dp)
         cfg.free(ds)
+
+
+@pytest.mark.parametrize("log_n", [10, 14, 16, 18])
+def test_lone_call_reduce_groups_agree_with_pipelined_geometry(cfg, log_n):
+    """A lone call picks the group size of the row / column sums of the window reduction level by level (short chains,
+    more launches); pipelined instances use groups of 16.  Every choice must give the same point: lone calls with the
+    minimum group pinned to 4, 8 and 16 (MSM_AMD_REDUCE_GROUP), the default, and the same instance inside a batch of
+    three (pipelined geometry); uniform scalars and all-equal scalars (one bucket per window holds everything)."""
+    import os
+    n = 1 << log_n
+    dp, ds = cfg.generate_instance(o.SEED_BASE + 4400 + log_n, n, True)
+    k = 0x2A2B2C2D2E2F30313233343536373839404142434445464748495051525354 % o.R_ORDER
+    d_eq = cfg.alloc(32 * n)
+    cfg.to_device(d_eq, o.encode_scalar_h2c(k) * n)
+    try:
+        batch = cfg.msm_batch_device([ds, d_eq, ds], [dp, dp, dp], [n, n, n])
+        assert batch[0] == batch[2]
+        if log_n <= 14:
+            pb, sb = cfg.to_host(dp, 64 * n), cfg.to_host(ds, 32 * n)
+            assert o.decode_jacobian_mont_le(batch[0]) == o.decode_jacobian_mont_le(co.msm_best(sb, pb, n))
+        old = os.environ.get("MSM_AMD_REDUCE_GROUP")
+        try:
+            for g in (None, "4", "8", "16"):
+                if g is None:
+                    os.environ.pop("MSM_AMD_REDUCE_GROUP", None)
+                else:
+                    os.environ["MSM_AMD_REDUCE_GROUP"] = g
+                assert cfg.msm_batch_device([ds], [dp], [n])[0] == batch[0], g
+                assert cfg.msm_batch_device([d_eq], [dp], [n])[0] == batch[1], g
+        finally:
+            if old is None:
+                os.environ.pop("MSM_AMD_REDUCE_GROUP", None)
+            else:
+                os.environ["MSM_AMD_REDUCE_GROUP"] = old
+    finally:
+        cfg.free(dp)
+        cfg.free(ds)
+        cfg.free(d_eq)

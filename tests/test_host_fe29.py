@@ -134,3 +134,26 @@ def test_ec29_affine_plus_affine_start_of_item(msm_pkg):
     flat = msm_pkg.test_op_host(msm_pkg.OP_EC29_MMADD, a, b, len(cases))
     got = [decode_be32_affine(flat[24 * i:24 * i + 24]) for i in range(len(cases))]
     assert got == [_mmadd_expect(p, q) for p, q in cases]
+
+
+def test_host64_field_and_group_ops(msm_pkg):
+    """The 4 x 64-bit host arithmetic of the CPU tail (csrc/host_fq64.h: window Horner pass + normalisation of every
+    MSM) against the big-int oracle AND, coordinate for coordinate, against the portable 8 x 32-bit host code it
+    replaced (same formulas, so the projective coordinates must be identical, not only the point)."""
+    rng = random.Random(64)
+    a, b = _vals(rng, 400), list(reversed(_vals(rng, 400)))
+    assert _run(msm_pkg, msm_pkg.OP_H64_FP_MUL, a, b) == [x * y % o.P for x, y in zip(a, b)]
+    assert _run(msm_pkg, msm_pkg.OP_H64_FP_ADD, a, b) == [(x + y) % o.P for x, y in zip(a, b)]
+    assert _run(msm_pkg, msm_pkg.OP_H64_FP_SUB, a, b) == [(x - y) % o.P for x, y in zip(a, b)]
+    cases = _ec_cases(rng)
+    cnt = len(cases)
+    ja = sum((o.encode_point_be32(rand_jac(rng, p)) for p, _ in cases), [])
+    jb = sum((o.encode_point_be32(rand_jac(rng, q)) for _, q in cases), [])
+    flat = msm_pkg.test_op_host(msm_pkg.OP_H64_EC_ADD, ja, jb, cnt)
+    assert [decode_be32_affine(flat[24 * i:24 * i + 24]) for i in range(cnt)] == [o.aff_add(p, q) for p, q in cases]
+    assert flat == msm_pkg.test_op_host(msm_pkg.OP_EC_ADD, ja, jb, cnt)
+    flat = msm_pkg.test_op_host(msm_pkg.OP_H64_EC_DBL, ja, jb, cnt)
+    assert [decode_be32_affine(flat[24 * i:24 * i + 24]) for i in range(cnt)] == [o.aff_add(p, p) for p, _ in cases]
+    assert flat == msm_pkg.test_op_host(msm_pkg.OP_EC_DBL, ja, jb, cnt)
+    with pytest.raises(msm_pkg.MsmError):
+        msm_pkg.test_op_host(32, ja, jb, cnt)

@@ -1,0 +1,31 @@
+"""Latency of ONE blocking device-resident MSM call per size (development aid): median wall time and stage spans."""
+import importlib
+import os
+import statistics
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+m = importlib.import_module("metal-msm-gpu-acceleration_amd")
+
+logs = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "16,18,20").split(",")]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+cfg = m.setup_metal_state()
+for lg in logs:
+    n = 1 << lg
+    dp, ds = cfg.generate_instance(0xB2540000, n, True)
+    for _ in range(6):   # every workspace allocated
+        out = cfg.msm_batch_device([ds], [dp], [n])[0]
+    wall, acc = [], {}
+    for r in range(reps):
+        t0 = time.perf_counter()
+        out = cfg.msm_batch_device([ds], [dp], [n])[0]
+        wall.append((time.perf_counter() - t0) * 1e3)
+        t = cfg.timings()
+        for k in ("convert_ms", "digits_ms", "sort_ms", "accumulate_ms", "reduce_ms", "final_ms"):
+            acc.setdefault(k, []).append(getattr(t, k))
+    med = {k: statistics.median(v) for k, v in acc.items()}
+    print(f"log={lg} c={t.window_size} lone call: median {statistics.median(wall):.4f} ms, min {min(wall):.4f} ms | "
+          + " ".join(f"{k[:-3]}={v:.3f}" for k, v in med.items()) + f" | x={out[:8].hex()}", flush=True)
+    cfg.free(dp)
+    cfg.free(ds)
