@@ -101,8 +101,13 @@ const char* msm_amd_last_error(const msm_amd_ctx* ctx);
 int msm_amd_set_window_size(msm_amd_ctx* ctx, uint32_t window_size);
 /* The automatic choice for n points.  Reference policy: 3 if n < 32 else 15 (msm.rs:135-141).  This library: 3 below
  * 32 points, then the window measured fastest on MI355X per size class (5 up to 2^14 points, 13 up to 2^16, 15 up
- * to 2^18, 16 at 2^19, 17 beyond); this function is the only source of truth -- results never depend on it. */
+ * to 2^18, 16 at 2^19, 17 beyond) for instances that run PIPELINED (batches, or a call submitted while others are
+ * in flight); results never depend on it. */
 uint32_t msm_amd_auto_window_size(size_t n);
+/* The automatic choice for ONE instance submitted while nothing else is in flight (a blocking gpu_msm_h2c call):
+ * such a call is a chain of launches and dependent additions, not a throughput problem, and wider windows with a
+ * full top digit are faster (5 up to 2^6 points, 8 up to 2^12, 15 up to 2^18, 17 beyond). */
+uint32_t msm_amd_auto_window_size_lone(size_t n);
 
 /* ---- whole-MSM entry points: host buffers ---------------------------------------------------- */
 /* gpu_msm_h2c::<G1Affine, .., Fr>(scalars, points) -> G1 (msm.rs:352-364).

@@ -33,7 +33,7 @@ def op_is_point(op):
 # every symbol include/msm_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "msm_amd_init", "msm_amd_init_reusable", "msm_amd_get_global", "msm_amd_destroy", "msm_amd_strerror",
-    "msm_amd_last_error", "msm_amd_set_window_size", "msm_amd_auto_window_size", "msm_amd_gpu_msm_h2c",
+    "msm_amd_last_error", "msm_amd_set_window_size", "msm_amd_auto_window_size", "msm_amd_auto_window_size_lone", "msm_amd_gpu_msm_h2c",
     "msm_amd_gpu_msm_h2c_sync", "msm_amd_cpu_dispatch_below", "msm_amd_host_register", "msm_amd_host_unregister",
     "msm_amd_metal_msm_ark", "msm_amd_msm", "msm_amd_msm_batch", "msm_amd_msm_best", "msm_amd_gpu_with_cpu",
     "msm_amd_reference_split", "msm_amd_msm_device",
@@ -116,6 +116,8 @@ def _lib():
         L.msm_amd_set_window_size.argtypes = [c_void_p, c_uint32]
         L.msm_amd_auto_window_size.argtypes = [c_size_t]
         L.msm_amd_auto_window_size.restype = c_uint32
+        L.msm_amd_auto_window_size_lone.argtypes = [c_size_t]
+        L.msm_amd_auto_window_size_lone.restype = c_uint32
         L.msm_amd_gpu_msm_h2c.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
         L.msm_amd_metal_msm_ark.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
         L.msm_amd_gpu_msm_h2c_sync.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, AFTER_SORT_FN, c_void_p, c_void_p]

@@ -208,6 +208,22 @@ uint32_t auto_window(size_t n) {
   return kMaxWindow;
 }
 
+// Window size of a LONE call (one instance, nothing else in flight: lone_call()).  The pipelined policy above minimises
+// GPU work per MSM; a lone call is a chain of launches and of dependent point additions, where a wide window costs
+// little (the window reduction is a fixed number of levels, the accumulate kernel is far from filling the machine)
+// and a narrow top window costs a lot (split buckets -> the combine pass).  Median ms of one blocking device-resident
+// call on MI355X (tools/lone_latency.py, profiles/r02_lone_call_window_sweep.txt), best | pipelined policy:
+//   2^8 c=8 0.346 | c=5 0.357     2^12 c=8 0.446 | c=5 0.538     2^14 c=15 0.487 | c=5 0.596
+//   2^16 c=15 0.543 | c=13 0.661  2^18 c=15 0.810 (16: 0.796)    2^19 c=17 1.201 | c=16 1.253
+uint32_t auto_window_lone(size_t n) {
+  if (n < 32) return 3;
+  const uint32_t l = floor_log2(n);
+  if (l <= 6) return 5;
+  if (l <= 12) return 8;
+  if (l <= 18) return 15;
+  return kMaxWindow;
+}
+
 // `windows` = 0: the per-call pipeline (every signed-digit window owns a bucket set).  `windows` = W_digits > 0: the
 // precomputed-table pipeline, where the [W_digits][n_scalars] digit matrix is sorted as ONE window of
 // W_digits * n_scalars entries whose "point index" addresses the table entry 2^(c w) P_i directly.
@@ -528,7 +544,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
     if (!tb) return fail(ctx, MSM_AMD_INPUT_ERROR, "not a table handle of this ctx");
     if (n != tb->n) return fail(ctx, MSM_AMD_INPUT_ERROR, "n differs from the number of points the tables hold");
   }
-  const uint32_t c = tb ? tb->c : (ctx->forced_window ? ctx->forced_window : auto_window(n));
+  const uint32_t c = tb ? tb->c : (ctx->forced_window ? ctx->forced_window : (lone ? auto_window_lone(n) : auto_window(n)));
   Plan p = tb ? make_plan(n, c, tb->W) : make_plan(n, c);
   if (lone) p.red_group = pick_reduce_group(p);
   *plan_out = p;
@@ -1060,6 +1076,7 @@ int msm_amd_set_window_size(msm_amd_ctx* ctx, uint32_t window_size) {
 }
 
 uint32_t msm_amd_auto_window_size(size_t n) { return auto_window(n); }
+uint32_t msm_amd_auto_window_size_lone(size_t n) { return auto_window_lone(n); }
 
 int msm_amd_msm_batch(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
                       const void* const* scalars, const void* const* points, const size_t* n, void* out) {

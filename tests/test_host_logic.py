@@ -45,6 +45,13 @@ def test_window_policy(msm_pkg):
     # none of the chosen windows leaves a top digit of fewer than 4 bits (all points of that window in <= 8 buckets)
     for c in set(ws):
         assert 254 - (254 // c) * c >= 4 or 254 % c == 0
+    # a lone call (one instance, nothing else in flight) has its own policy: latency, not GPU work per MSM
+    lone = [L.msm_amd_auto_window_size_lone(1 << k) for k in range(5, 25)]
+    assert L.msm_amd_auto_window_size_lone(31) == 3 and lone == sorted(lone)
+    assert L.msm_amd_auto_window_size_lone(1 << 12) == 8 and L.msm_amd_auto_window_size_lone(1 << 16) == 15
+    assert L.msm_amd_auto_window_size_lone(1 << 18) == 15 and L.msm_amd_auto_window_size_lone(1 << 19) == 17
+    for c in set(lone):
+        assert 254 - (254 // c) * c >= 4 or 254 % c == 0
 
 
 def test_algorithmic_bytes_match_survey(msm_pkg):

@@ -11,12 +11,19 @@ m = importlib.import_module("metal-msm-gpu-acceleration_amd")
 logs = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "16,18,20").split(",")]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 cfg = m.setup_metal_state()
+if os.environ.get("LONE_C"):
+    cfg.set_window_size(int(os.environ["LONE_C"]))
 for lg in logs:
     n = 1 << lg
     dp, ds = cfg.generate_instance(0xB2540000, n, True)
     for _ in range(6):   # every workspace allocated
         out = cfg.msm_batch_device([ds], [dp], [n])[0]
-    wall, acc = [], {}
+    wall, acc, sub = [], {}, []
+    for r in range(reps):   # the same call split into its two halves: how long does the host need to enqueue it?
+        t0 = time.perf_counter()
+        h = cfg.submit_batch_device([ds], [dp], [n])
+        sub.append((time.perf_counter() - t0) * 1e3)
+        cfg.wait_batch(h)
     for r in range(reps):
         t0 = time.perf_counter()
         out = cfg.msm_batch_device([ds], [dp], [n])[0]
@@ -25,7 +32,8 @@ for lg in logs:
         for k in ("convert_ms", "digits_ms", "sort_ms", "accumulate_ms", "reduce_ms", "final_ms"):
             acc.setdefault(k, []).append(getattr(t, k))
     med = {k: statistics.median(v) for k, v in acc.items()}
-    print(f"log={lg} c={t.window_size} lone call: median {statistics.median(wall):.4f} ms, min {min(wall):.4f} ms | "
+    print(f"log={lg} c={t.window_size} lone call: median {statistics.median(wall):.4f} ms, min {min(wall):.4f} ms, "
+          f"enqueue {statistics.median(sub):.4f} ms | "
           + " ".join(f"{k[:-3]}={v:.3f}" for k, v in med.items()) + f" | x={out[:8].hex()}", flush=True)
     cfg.free(dp)
     cfg.free(ds)
