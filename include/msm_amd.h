@@ -100,7 +100,7 @@ const char* msm_amd_last_error(const msm_amd_ctx* ctx);
 /* encode_instances' `window_size: Option<u32>` (msm.rs:130-141): 0 = automatic, else 3..17. */
 int msm_amd_set_window_size(msm_amd_ctx* ctx, uint32_t window_size);
 /* The automatic choice for n points.  Reference policy: 3 if n < 32 else 15 (msm.rs:135-141).  This library: 3 below
- * 32 points, then the window measured fastest on MI355X per size class (5 up to 2^14 points, 13 up to 2^16, 15 up
+ * 32 points, then the window measured fastest on MI355X per size class (5 up to 2^14 points, 15 up
  * to 2^18, 16 at 2^19, 17 beyond) for instances that run PIPELINED (batches, or a call submitted while others are
  * in flight); results never depend on it. */
 uint32_t msm_amd_auto_window_size(size_t n);

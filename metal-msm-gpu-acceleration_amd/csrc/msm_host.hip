@@ -74,6 +74,7 @@ struct Workspace {
 };
 
 constexpr int kWorkspaces = 4;
+constexpr int kReduceStreams = 2;
 constexpr int kMaxBatches = 4;   // batches that may be in flight between submit and wait
 
 struct Batch {
@@ -95,10 +96,12 @@ struct msm_amd_tables {
 struct msm_amd_ctx {
   int device = 0;
   hipStream_t stream = nullptr;          // main stream: conversion, digits, sort, accumulate; stage entry points
-  hipStream_t reduce_stream = nullptr;   // side stream: window reduction + copy of the partial points
-  hipStream_t reduce_stream2 = nullptr;  // consecutive instances alternate between the two reduce streams: the tail
-                                         // of an instance is a chain of four latency-bound kernels that is as long as
-                                         // one accumulate, so two of them must be able to overlap
+  hipStream_t reduce_streams[kReduceStreams] = {};   // side streams: window reduction + copy of the partial points.
+                                         // Consecutive instances alternate between them: the tail of an instance is a
+                                         // chain of latency-bound kernels that is as long as one accumulate, so two
+                                         // of them must be able to overlap.  (More streams than the four hardware
+                                         // queues HIP gives a process -- main, front, two reduce -- share a queue
+                                         // with the accumulate grid and wait behind it: measured, 1.6x slower.)
   bool alt_reduce = true;                // MSM_AMD_ALT_REDUCE=0: one reduce stream
   bool low_occ_accumulate = true;        // 2-wave accumulate variant (set from overlap_front; MSM_AMD_LOW_OCC overrides)
   uint32_t seq = 0;
@@ -138,8 +141,7 @@ void drain_streams(msm_amd_ctx* ctx) {
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   (void)hipStreamSynchronize(ctx->front_stream);
   (void)hipStreamSynchronize(ctx->stream);
-  (void)hipStreamSynchronize(ctx->reduce_stream);
-  (void)hipStreamSynchronize(ctx->reduce_stream2);
+  for (hipStream_t rs : ctx->reduce_streams) (void)hipStreamSynchronize(rs);
   (void)hipGetLastError();
 }
 
@@ -202,8 +204,7 @@ uint32_t auto_window(size_t n) {
   if (n < 32) return 3;   // msm.rs:137-138
   const uint32_t l = floor_log2(n);
   if (l <= 14) return 5;
-  if (l <= 16) return 13;
-  if (l <= 18) return 15;
+  if (l <= 18) return 15;   // 2^16 in batches of 40 after the 64-bit host pass: c=15 0.207, c=13 0.233, c=16 0.246 ms per MSM
   if (l == 19) return 16;   // u32 digits from here on
   return kMaxWindow;
 }
@@ -605,7 +606,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   hipStream_t fs = front_stream_of(ctx, lone);
   hipStream_t rs = (lone || !ctx->overlap_reduce)
                        ? st
-                       : ((ctx->alt_reduce && (ctx->seq++ & 1u)) ? ctx->reduce_stream2 : ctx->reduce_stream);
+                       : ctx->reduce_streams[ctx->alt_reduce ? ctx->seq++ % kReduceStreams : 0];
   if (w.acc_pending && (fs != st || lone)) {   // the previous accumulate in this workspace still reads its plan ...
     HIP_TRY(ctx, hipStreamWaitEvent(fs, w.acc_done, 0));
   }
@@ -742,26 +743,55 @@ int submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, s
   return MSM_AMD_OK;
 }
 
+// Host threads for the CPU tail (window Horner pass + normalisation, ~0.11 ms per instance) of one batch.  Batches of
+// small MSMs are bound by it: 40 x 2^12 points take 0.16 ms per MSM on one thread, of which 0.11 ms is this pass and
+// 0.05 ms the enqueue.  One thread per 4 instances, at most 4 and at most half of the cores; MSM_AMD_FINISH_THREADS
+// overrides (1 = the calling thread only).
+unsigned finish_threads(size_t n_inst) {
+  if (const char* e = std::getenv("MSM_AMD_FINISH_THREADS")) return (unsigned)std::max(1, std::atoi(e));
+  const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+  return (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)4, n_inst / 4, (size_t)hw / 2}));
+}
+
 int wait_batch(msm_amd_ctx* ctx, int ticket) {
   if (!ctx || ticket < 0 || ticket >= kMaxBatches || !ctx->batches[ticket].active)
     return fail(ctx, MSM_AMD_INPUT_ERROR, "unknown batch ticket");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   Batch& B = ctx->batches[ticket];
   ctx->timings = msm_amd_timings{};
+  struct Done {
+    hipError_t err = hipSuccess;
+    float final_ms = 0;
+  };
+  std::vector<Done> done(B.n_inst);
+  // instance i: wait for its partial sums, Horner pass, result; instances are independent, each writes its own slot
+  auto finish_from = [&](size_t first, size_t stride, bool set_device) {
+    if (set_device && hipSetDevice(ctx->device) != hipSuccess) {
+      for (size_t i = first; i < B.n_inst; i += stride) done[i].err = hipErrorInvalidDevice;
+      return;
+    }
+    for (size_t i = first; i < B.n_inst; i += stride) {
+      InstanceSlot& s = B.slots[i];
+      done[i].err = wait_event(s.ev[EV_REDUCE]);
+      if (done[i].err != hipSuccess) continue;
+      const auto t0 = std::chrono::steady_clock::now();
+      const Jacobian res = normalise(host_combine(s.h_partial, B.plans[i]));
+      done[i].final_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      std::memcpy((uint8_t*)B.out + i * 96, &res, 96);
+    }
+  };
+  const unsigned T = std::min<size_t>(finish_threads(B.n_inst), B.n_inst);
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < T; ++t) pool.emplace_back(finish_from, (size_t)t, (size_t)T, true);
+  finish_from(0, T, false);
+  for (std::thread& th : pool) th.join();
   for (size_t i = 0; i < B.n_inst; ++i) {
-    InstanceSlot& s = B.slots[i];
-    const hipError_t e = wait_event(s.ev[EV_REDUCE]);
-    if (e != hipSuccess) {   // release the ticket on every exit: a failed wait must not block later submits
+    if (done[i].err != hipSuccess) {   // release the ticket on every exit: a failed wait must not block later submits
       drain_streams(ctx);
       B.active = false;
-      return fail(ctx, MSM_AMD_PIPELINE_ERROR, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+      return fail(ctx, MSM_AMD_PIPELINE_ERROR, std::string("hipEventSynchronize: ") + hipGetErrorString(done[i].err));
     }
-    const auto t0 = std::chrono::steady_clock::now();
-    const Jacobian res = normalise(host_combine(s.h_partial, B.plans[i]));
-    const float final_ms =
-        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    std::memcpy((uint8_t*)B.out + i * 96, &res, 96);
-    accumulate_timings(ctx, s, B.plans[i], final_ms, B.n_inst);
+    accumulate_timings(ctx, B.slots[i], B.plans[i], done[i].final_ms, B.n_inst);
   }
   B.active = false;
   return MSM_AMD_OK;
@@ -934,12 +964,12 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   // the short front-end / reduction kernels get priority over the long accumulate grid
   bool ok = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_least) == hipSuccess &&
-            hipStreamCreateWithPriority(&ctx->reduce_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
-            hipStreamCreateWithPriority(&ctx->reduce_stream2, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipStreamCreateWithPriority(&ctx->front_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->uploaded[0], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->uploaded[1], hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; ok && k < kReduceStreams; ++k)
+    ok = hipStreamCreateWithPriority(&ctx->reduce_streams[k], hipStreamNonBlocking, prio_greatest) == hipSuccess;
   for (int k = 0; ok && k < kWorkspaces; ++k)
     ok = hipEventCreateWithFlags(&ctx->ws[k].front_done, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&ctx->ws[k].acc_done, hipEventDisableTiming) == hipSuccess &&
@@ -953,8 +983,8 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   if (rc) {
     std::fprintf(stderr, "msm_amd: %s\n", ctx->last_error.c_str());
     (void)hipStreamDestroy(ctx->stream);
-    (void)hipStreamDestroy(ctx->reduce_stream);
-    (void)hipStreamDestroy(ctx->reduce_stream2);
+    for (hipStream_t rs : ctx->reduce_streams)
+      if (rs) (void)hipStreamDestroy(rs);
     (void)hipStreamDestroy(ctx->front_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
     (void)hipEventDestroy(ctx->uploaded[0]);
@@ -994,8 +1024,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->front_stream);
   (void)hipStreamSynchronize(ctx->stream);
-  (void)hipStreamSynchronize(ctx->reduce_stream);
-  (void)hipStreamSynchronize(ctx->reduce_stream2);
+  for (hipStream_t rs : ctx->reduce_streams) (void)hipStreamSynchronize(rs);
   for (int k = 0; k < kWorkspaces; ++k) {
     Workspace& w = ctx->ws[k];
     DeviceBuf* bufs[] = {&w.digits, &w.coarse_cnt, &w.region_start, &w.tmp_idx, &w.tmp_fine, &w.tmp_idx2, &w.tmp_fine2, &w.mid_cnt, &w.region_start2, &w.bsize, &w.bstart, &w.istart, &w.win_items, &w.size_bins, &w.sorted,
@@ -1025,8 +1054,8 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   for (auto& r : ctx->host_regs) (void)hipHostUnregister(const_cast<void*>(r.first));   // left registered by the caller
   (void)hipGetLastError();
   (void)hipStreamDestroy(ctx->stream);
-  (void)hipStreamDestroy(ctx->reduce_stream);
-  (void)hipStreamDestroy(ctx->reduce_stream2);
+  for (hipStream_t rs : ctx->reduce_streams)
+    if (rs) (void)hipStreamDestroy(rs);
   (void)hipStreamDestroy(ctx->front_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   for (hipEvent_t e : ctx->uploaded)
@@ -1506,8 +1535,7 @@ int msm_amd_synchronize(msm_amd_ctx* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->front_stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->reduce_stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->reduce_stream2));
+  for (hipStream_t rs : ctx->reduce_streams) HIP_TRY(ctx, hipStreamSynchronize(rs));
   return MSM_AMD_OK;
 }
 

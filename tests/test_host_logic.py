@@ -37,7 +37,7 @@ def test_window_policy(msm_pkg):
     L = msm_pkg.lib()
     assert L.msm_amd_auto_window_size(1) == 3 and L.msm_amd_auto_window_size(31) == 3     # msm.rs:137-138
     assert L.msm_amd_auto_window_size(32) == 5
-    assert L.msm_amd_auto_window_size(1 << 16) == 13 and L.msm_amd_auto_window_size(1 << 18) == 15
+    assert L.msm_amd_auto_window_size(1 << 16) == 15 and L.msm_amd_auto_window_size(1 << 18) == 15
     assert L.msm_amd_auto_window_size(1 << 19) == 16                                                  # u32 digits
     assert L.msm_amd_auto_window_size(1 << 20) == 17 and L.msm_amd_auto_window_size(1 << 24) == 17
     ws = [L.msm_amd_auto_window_size(1 << k) for k in range(5, 25)]
