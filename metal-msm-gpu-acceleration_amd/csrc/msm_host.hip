@@ -963,13 +963,18 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   // the short front-end / reduction kernels get priority over the long accumulate grid
-  bool ok = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_least) == hipSuccess &&
+  // CREATION ORDER MATTERS: HIP maps streams onto four hardware queues in creation order, so the fifth stream (copy,
+  // idle in device-resident runs) shares the queue of the first (main).  With the reduce streams created last, one
+  // of them shared the accumulate grid's queue and every second window reduction waited behind it: 760 -> 720 MSM/s
+  // on the same box (profiles/r02_stream_creation_order_ab.txt).
+  bool ok = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_least) == hipSuccess;
+  for (int k = 0; ok && k < kReduceStreams; ++k)
+    ok = hipStreamCreateWithPriority(&ctx->reduce_streams[k], hipStreamNonBlocking, prio_greatest) == hipSuccess;
+  ok = ok &&
             hipStreamCreateWithPriority(&ctx->front_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->uploaded[0], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->uploaded[1], hipEventDisableTiming) == hipSuccess;
-  for (int k = 0; ok && k < kReduceStreams; ++k)
-    ok = hipStreamCreateWithPriority(&ctx->reduce_streams[k], hipStreamNonBlocking, prio_greatest) == hipSuccess;
   for (int k = 0; ok && k < kWorkspaces; ++k)
     ok = hipEventCreateWithFlags(&ctx->ws[k].front_done, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&ctx->ws[k].acc_done, hipEventDisableTiming) == hipSuccess &&
