@@ -966,7 +966,8 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   // CREATION ORDER MATTERS: HIP maps streams onto four hardware queues in creation order, so the fifth stream (copy,
   // idle in device-resident runs) shares the queue of the first (main).  With the reduce streams created last, one
   // of them shared the accumulate grid's queue and every second window reduction waited behind it: 760 -> 720 MSM/s
-  // on the same box (profiles/r02_stream_creation_order_ab.txt).
+  // on the same box (profiles/r02_stream_creation_order_ab.txt).  The copy stream is best off on the main stream's
+  // queue as well: on a reduce stream's queue the host-slice batches lose 4 %, on the front stream's 18 %.
   bool ok = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_least) == hipSuccess;
   for (int k = 0; ok && k < kReduceStreams; ++k)
     ok = hipStreamCreateWithPriority(&ctx->reduce_streams[k], hipStreamNonBlocking, prio_greatest) == hipSuccess;
