@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak test of the multi-stream pipeline: batches of mixed sizes and windows, four batches in flight, every result
+"""Soak test of the multi-stream pipeline: batches of 1-12 instances of mixed sizes and windows, four batches in flight, lone calls in between, every result
 compared with the C oracle (restated msm_best).  Development aid; the graded tests live in tests/.
 
   python tools/soak.py [--rounds 60] [--seed 1]
@@ -34,7 +34,7 @@ def main():
         cfg.set_window_size(rng.choice([0, 0, 0, 5, 9, 13, 15, 16, 17]))
         handles = []
         for b in range(4):                            # four batches in flight, 1..5 instances each, mixed sizes
-            pick = [rng.choice(sizes) for _ in range(rng.randint(1, 5))]
+            pick = [rng.choice(sizes) for _ in range(rng.choice([1, 2, 3, 5, 8, 12]))]   # 8+: threaded host passes
             h = cfg.submit_batch_device([pool[n][1] for n in pick], [pool[n][0] for n in pick], pick)
             handles.append((h, pick))
         for h, pick in rng.sample(handles, len(handles)):   # collected in random order
@@ -42,6 +42,11 @@ def main():
             for n, out in zip(pick, outs):
                 assert o.decode_jacobian_mont_le(out) == pool[n][2], (r, n)
                 checked += 1
+        if r % 3 == 0:                                # nothing in flight now: a LONE call (one stream, lone window policy)
+            n = rng.choice(sizes)
+            out = cfg.msm_batch_device([pool[n][1]], [pool[n][0]], [n])[0]
+            assert o.decode_jacobian_mont_le(out) == pool[n][2], ("lone", r, n)
+            checked += 1
     cfg.set_window_size(0)
     print(f"soak ok: {a.rounds} rounds, {checked} MSMs checked against the oracle")
 
