@@ -548,6 +548,9 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   const uint32_t c = tb ? tb->c : (ctx->forced_window ? ctx->forced_window : (lone ? auto_window_lone(n) : auto_window(n)));
   Plan p = tb ? make_plan(n, c, tb->W) : make_plan(n, c);
   if (lone) p.red_group = pick_reduce_group(p);
+  // the tile-staged scatter (1024-thread workgroups, 60 VGPRs, 64 KB of LDS) is for a sort that has the machine to
+  // itself; beside a resident accumulate grid it is slower than the plain scatter (4 x 2^22 points: 6.15 vs 5.65 ms per MSM)
+  if (!lone && !std::getenv("MSM_AMD_TILED")) p.tiled = 0;
   *plan_out = p;
   int rc;
   if ((rc = slot_prepare(ctx, slot, p.partial_count))) return rc;
@@ -797,8 +800,78 @@ int wait_batch(msm_amd_ctx* ctx, int ticket) {
   return MSM_AMD_OK;
 }
 
+// A LONE call of many points runs as ONE PIPELINED BATCH of sub-instances over point ranges (the algebra of the
+// reference's GPU + CPU split, msm.rs:385-419: the MSM of a union of point ranges is the sum of the MSMs).  Alone, an
+// instance is a serial chain upload -> conversion / digits / sort -> accumulate -> reduction; as a batch, the front end
+// (and, from host buffers, the upload) of range k + 1 overlaps the accumulate kernel of range k.  Costs: one window
+// reduction and one host Horner pass per range (overlapped, except the last) and a final addition of `parts` points.
+// Thresholds measured on MI355X (profiles/r02_lone_call_split.txt); MSM_AMD_SPLIT=<parts> forces a count, 1 disables.
+unsigned split_parts(const msm_amd_ctx* ctx, int point_layout, size_t n, bool host_buffers) {
+  if (point_layout == MSM_AMD_POINT_TABLES || !lone_call(ctx, 1)) return 1;
+  unsigned parts = 1;
+  if (const char* e = std::getenv("MSM_AMD_SPLIT")) {
+    parts = (unsigned)std::max(1, std::min(8, std::atoi(e)));
+  } else {
+    const uint32_t l = floor_log2(n);
+    if (host_buffers) parts = l >= 22 ? 8 : (l >= 20 ? 4 : (l >= 19 ? 2 : 1));   // the upload overlaps too
+    else parts = l >= 24 ? 8 : (l == 23 ? 4 : 1);
+  }
+  while (parts > 1 && n / parts < 4096) parts >>= 1;
+  return parts;
+}
+
+int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst, const void* const* scalars,
+                   const void* const* points, const size_t* n, void* out);
+int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
+                     const void* const* d_scalars, const void* const* d_points, const size_t* n, void* out_host);
+
+int run_split(msm_amd_ctx* ctx, int scalar_layout, int point_layout, const void* scalars, const void* points, size_t n,
+              unsigned parts, void* out, bool host_buffers) {
+  const size_t sb = scalar_bytes(scalar_layout), pb = point_bytes(point_layout);
+  std::vector<const void*> sp(parts), pp(parts);
+  std::vector<size_t> nn(parts);
+  std::vector<uint8_t> outs((size_t)parts * 96);
+  for (unsigned k = 0; k < parts; ++k) {
+    const size_t b = n * k / parts, e = n * (k + 1) / parts;
+    sp[k] = (const uint8_t*)scalars + sb * b;
+    pp[k] = (const uint8_t*)points + pb * b;
+    nn[k] = e - b;
+  }
+  int rc;
+  if (host_buffers) {
+    rc = run_batch_host(ctx, scalar_layout, point_layout, parts, sp.data(), pp.data(), nn.data(), outs.data());
+  } else {
+    int ticket = -1;
+    rc = submit_batch_device(ctx, scalar_layout, point_layout, parts, sp.data(), pp.data(), nn.data(), outs.data(),
+                             &ticket, 0);
+    if (!rc) rc = wait_batch(ctx, ticket);
+  }
+  if (rc) return rc;
+  h64::Jac acc = h64::identity();
+  for (unsigned k = 0; k < parts; ++k) {
+    h64::Jac p;
+    std::memcpy(&p, outs.data() + (size_t)k * 96, 96);
+    acc = h64::jadd(acc, p);
+  }
+  const h64::Jac res = h64::normalise(acc);
+  std::memcpy(out, &res, 96);
+  // stage spans of the call = sums over its ranges (wait_batch / run_batch_host report per-instance averages)
+  msm_amd_timings& T = ctx->timings;
+  const float P = (float)parts;
+  T.convert_ms *= P; T.digits_ms *= P; T.sort_ms *= P; T.accumulate_ms *= P; T.accumulate_kernel_ms *= P;
+  T.reduce_ms *= P; T.final_ms *= P; T.total_gpu_ms *= P;
+  T.n = (uint32_t)n;
+  T.reserved = parts;
+  return MSM_AMD_OK;
+}
+
 int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst,
                      const void* const* d_scalars, const void* const* d_points, const size_t* n, void* out_host) {
+  if (n_inst == 1 && ctx && d_scalars && d_points && n && d_scalars[0] && d_points[0]) {
+    const unsigned parts = split_parts(ctx, point_layout, n[0], false);
+    if (parts > 1)
+      return run_split(ctx, scalar_layout, point_layout, d_scalars[0], d_points[0], n[0], parts, out_host, false);
+  }
   int ticket = -1;
   int rc = submit_batch_device(ctx, scalar_layout, point_layout, n_inst, d_scalars, d_points, n, out_host, &ticket);
   if (rc) return rc;
@@ -816,6 +889,10 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
   // only the scalars (32 bytes per point instead of 96) cross PCIe -- the repeated-SRS case
   const bool dev_points = point_layout == MSM_AMD_POINT_PREPARED || point_layout == MSM_AMD_POINT_TABLES;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n_inst == 1 && scalars[0] && points[0] && n[0]) {   // a lone call of many points: pipelined point ranges
+    const unsigned parts = split_parts(ctx, point_layout, n[0], true);
+    if (parts > 1) return run_split(ctx, scalar_layout, point_layout, scalars[0], points[0], n[0], parts, out, true);
+  }
   for (size_t i = 0; i < n_inst; ++i) {
     if (n[i] == 0 || !scalars[i] || !points[i]) return fail(ctx, MSM_AMD_INPUT_ERROR, "n == 0 or null pointer");
     if (point_layout == MSM_AMD_POINT_PREPARED) {   // must really be device memory: a host array here would fault

@@ -56,8 +56,9 @@ def test_after_sort_callback_fires_before_accumulation_ends(cfg, msm_pkg):
     pts, sc = co.gen_instance(0xB2540000 + 77, n)
     ref = msm_pkg.gpu_msm_h2c(sc, pts, cfg)
     for _ in range(4):                            # steady state: every one of the ctx's four workspaces has been grown
-        assert msm_pkg.gpu_msm_h2c(sc, pts, cfg) == ref   # to this size (growing one frees and allocates device memory,
-    fired = []                                    # which synchronises the device in the middle of the enqueue)
+        assert msm_pkg.gpu_msm_h2c_sync(sc, pts, None, cfg) == ref   # to this size by the SAME (unsplit) path -- growing
+    fired = []                                    # one frees and allocates device memory, which synchronises the device in
+                                                  # the middle of the enqueue; gpu_msm_h2c splits 2^20 host points into ranges
     out = msm_pkg.gpu_msm_h2c_sync(sc, pts, lambda: fired.append(1), cfg)
     assert fired == [1]
     t = cfg.timings()

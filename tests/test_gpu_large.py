@@ -332,3 +332,79 @@ def test_lone_call_reduce_groups_agree_with_pipelined_geometry(cfg, log_n):
         cfg.free(dp)
         cfg.free(ds)
         cfg.free(d_eq)
+
+
+def _with_env(key, value, fn):
+    import os
+    old = os.environ.get(key)
+    if value is None:
+        os.environ.pop(key, None)
+    else:
+        os.environ[key] = value
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop(key, None)
+        else:
+            os.environ[key] = old
+
+
+@pytest.mark.parametrize("n", [1 << 15, (1 << 15) + 4099, 40003])
+def test_lone_call_split_into_pipelined_point_ranges(cfg, msm_pkg, n):
+    """A lone call of many points runs as a pipelined batch of point ranges whose results are added on the host
+    (run_split; automatic from 2^23 device-resident / 2^19 host points).  Forced here at oracle-checkable sizes with
+    MSM_AMD_SPLIT: every entry point that takes one instance -- device-resident, host buffers (h2c), msm_best, prepared
+    bases -- must return the unsplit result, which must be the oracle's; n not divisible by the part count, identity
+    points and zero scalars inside the ranges, all-equal scalars."""
+    rng = random.Random(n)
+    dp, ds = cfg.generate_instance(o.SEED_BASE + 5500 + (n & 0xFFF), n, True)
+    try:
+        pb, sb = bytearray(cfg.to_host(dp, 64 * n)), bytearray(cfg.to_host(ds, 32 * n))
+        for i in rng.sample(range(n), 20):
+            pb[64 * i:64 * i + 64] = bytes(64)                  # identity points
+        for i in rng.sample(range(n), 20):
+            sb[32 * i:32 * i + 32] = bytes(32)                  # zero scalars
+        pb, sb = bytes(pb), bytes(sb)
+        cfg.to_device(dp, pb)
+        cfg.to_device(ds, sb)
+        want = _with_env("MSM_AMD_SPLIT", "1", lambda: cfg.msm_batch_device([ds], [dp], [n])[0])
+        assert o.decode_jacobian_mont_le(want) == o.decode_jacobian_mont_le(co.msm_best(sb, pb, n))
+        d_prep = cfg.bases_upload(pb, n)
+        try:
+            for parts in ("2", "3", "5", "8"):
+                got = _with_env("MSM_AMD_SPLIT", parts, lambda: cfg.msm_batch_device([ds], [dp], [n])[0])
+                assert got == want, ("device", parts)
+                assert cfg.timings().reserved == min(int(parts), 8), parts
+                got = _with_env("MSM_AMD_SPLIT", parts, lambda: msm_pkg.gpu_msm_h2c(sb, pb, cfg))
+                assert got == want, ("host", parts)
+                got = _with_env("MSM_AMD_SPLIT", parts, lambda: msm_pkg.msm_best(sb, pb, cfg))
+                assert got == want, ("msm_best", parts)
+                got = _with_env("MSM_AMD_SPLIT", parts, lambda: cfg.msm_prepared(sb, d_prep, n))
+                assert got == want, ("prepared", parts)
+        finally:
+            cfg.free(d_prep)
+        k = 0x1111222233334444555566667777888899990000AAAABBBBCCCCDDDDEEEEFFFF % o.R_ORDER
+        eq = o.encode_scalar_h2c(k) * n
+        cfg.to_device(ds, eq)
+        one = _with_env("MSM_AMD_SPLIT", "1", lambda: cfg.msm_batch_device([ds], [dp], [n])[0])
+        four = _with_env("MSM_AMD_SPLIT", "4", lambda: cfg.msm_batch_device([ds], [dp], [n])[0])
+        assert one == four
+    finally:
+        cfg.free(dp)
+        cfg.free(ds)
+
+
+def test_lone_call_split_automatic_at_2p23(cfg):
+    """2^23 device-resident points split into four pipelined ranges by default; same point as the unsplit call."""
+    n = 1 << 23
+    dp, ds = cfg.generate_instance(o.SEED_BASE + 2323, n, True)
+    try:
+        got = cfg.msm_batch_device([ds], [dp], [n])[0]
+        assert cfg.timings().reserved == 4
+        want = _with_env("MSM_AMD_SPLIT", "1", lambda: cfg.msm_batch_device([ds], [dp], [n])[0])
+        assert cfg.timings().reserved == 1
+        assert got == want
+    finally:
+        cfg.free(dp)
+        cfg.free(ds)

@@ -16,6 +16,27 @@ if os.environ.get("LONE_C"):
 for lg in logs:
     n = 1 << lg
     dp, ds = cfg.generate_instance(0xB2540000, n, True)
+    if os.environ.get("LONE_HOST"):   # the same call from HOST buffers (gpu_msm_h2c): the upload is part of the call
+        hp, hs = cfg.to_host(dp, 64 * n), cfg.to_host(ds, 32 * n)
+        if os.environ.get("LONE_HOST") == "registered":
+            cfg.host_register(hp)
+            cfg.host_register(hs)
+        for _ in range(4):
+            out = m.gpu_msm_h2c(hs, hp, cfg)
+        wall = []
+        for r in range(reps):
+            t0 = time.perf_counter()
+            out = m.gpu_msm_h2c(hs, hp, cfg)
+            wall.append((time.perf_counter() - t0) * 1e3)
+        t = cfg.timings()
+        print(f"log={lg} c={t.window_size} parts={t.reserved} lone HOST-buffer call ({os.environ['LONE_HOST']}): median "
+              f"{statistics.median(wall):.4f} ms, min {min(wall):.4f} ms | x={out[:8].hex()}", flush=True)
+        if os.environ.get("LONE_HOST") == "registered":
+            cfg.host_unregister(hp)
+            cfg.host_unregister(hs)
+        cfg.free(dp)
+        cfg.free(ds)
+        continue
     for _ in range(6):   # every workspace allocated
         out = cfg.msm_batch_device([ds], [dp], [n])[0]
     wall, acc, sub = [], {}, []
@@ -32,7 +53,7 @@ for lg in logs:
         for k in ("convert_ms", "digits_ms", "sort_ms", "accumulate_ms", "reduce_ms", "final_ms"):
             acc.setdefault(k, []).append(getattr(t, k))
     med = {k: statistics.median(v) for k, v in acc.items()}
-    print(f"log={lg} c={t.window_size} lone call: median {statistics.median(wall):.4f} ms, min {min(wall):.4f} ms, "
+    print(f"log={lg} c={t.window_size} parts={t.reserved} lone call: median {statistics.median(wall):.4f} ms, min {min(wall):.4f} ms, "
           f"enqueue {statistics.median(sub):.4f} ms | "
           + " ".join(f"{k[:-3]}={v:.3f}" for k, v in med.items()) + f" | x={out[:8].hex()}", flush=True)
     cfg.free(dp)
