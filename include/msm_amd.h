@@ -76,7 +76,9 @@ typedef struct msm_amd_timings {
   uint32_t n;
   uint32_t window_size;
   uint32_t num_windows;
-  uint32_t reserved;            /* number of instances the averages were taken over */
+  uint32_t reserved;            /* number of instances the averages were taken over; for ONE large instance that ran
+                                   as pipelined point ranges (lone calls from 2^23 device-resident / 2^19 host points,
+                                   MSM_AMD_SPLIT): the number of ranges, and the stage fields are SUMS over them */
   float accumulate_kernel_ms;   /* accumulate_kernel alone (events directly around its launch) */
   float reserved2[3];           /* [0] = work items of the last instance's accumulate grid (exact below 2^24)
                                    [1] = 1 if bucket accumulation had not finished yet when the after_sort
@@ -113,7 +115,11 @@ uint32_t msm_amd_auto_window_size_lone(size_t n);
 /* gpu_msm_h2c::<G1Affine, .., Fr>(scalars, points) -> G1 (msm.rs:352-364).
  * scalars: n x 32 B MSM_AMD_SCALAR_MONT_LE; points: n x 64 B MSM_AMD_POINT_H2C_AFFINE;
  * out: 96 B Jacobian (x, y, z) Montgomery LE, normalised to z = R mod p, or z = 0 for the identity:
- * memcpy-compatible with bn256::G1 / G1Projective. */
+ * memcpy-compatible with bn256::G1 / G1Projective.
+ * A call of 2^19 points or more with nothing else in flight is executed as a pipelined batch of 2 / 4 / 8 point
+ * ranges (upload and sort of one range under the bucket accumulation of the previous one) whose results are added
+ * on the host -- same result, 17-38 % less wall time; every single-instance entry point does this (device-resident
+ * inputs from 2^23 points). */
 int msm_amd_gpu_msm_h2c(msm_amd_ctx* ctx, const void* scalars, const void* points, size_t n, void* out96);
 /* gpu_msm_h2c_sync(scalars, points, sync_pair: Arc<(Mutex<bool>, Condvar)>) (msm.rs:237-349): the same MSM, and
  * `after_sort(user)` is called once, on the calling thread, as soon as the sort stage of this MSM has finished on
