@@ -1,0 +1,39 @@
+"""The bench contract on a real GPU: `python bench.py` prints exactly ONE JSON line on stdout with the agreed fields."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                        "--cpu-seconds", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    x = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "rccl_ranks_seen"):
+        assert key in x, key
+    assert x["unit"] == "MSM/s" and x["n_gpus"] == 1 and x["steps"] == 3 and x["warmup"] == 1
+    assert x["higher_is_better"] is True and x["scaling"] == "weak" and x["vs_baseline"] is None
+    assert x["rccl_ranks_seen"] == 1 and x["value"] > 100 and "workload" in x["config"]
+    assert abs(x["value"] - 5 * 1000.0 / x["ms_per_step"]) / x["value"] < 0.02      # 5 instances per step
+    r = x["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.02 < r["frac"] < 1.0
+    c = x["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["bit_exact_vs_gpu"] is True
+    assert x["drop_in_caller"]["single_call_ms"]["resident_2^18"] < 5.0
