@@ -406,6 +406,22 @@ def drop_in_caller_figures(m, cfg, h_sc, h_pts, n, inst, expect):
             ts.append(time.perf_counter() - t0)
         return round(statistics.median(ts) * 1e3, 3)
 
+    def lone_registered(k):   # the same call on slices the caller page-locked once (msm_amd_host_register)
+        sc, pt = h_sc[0][:32 * k], h_pts[0][:64 * k]
+        cfg.host_register(sc)
+        cfg.host_register(pt)
+        try:
+            m.gpu_msm_h2c(sc, pt, cfg)
+            ts = []
+            for _ in range(7):
+                t0 = time.perf_counter()
+                m.gpu_msm_h2c(sc, pt, cfg)
+                ts.append(time.perf_counter() - t0)
+        finally:
+            cfg.host_unregister(sc)
+            cfg.host_unregister(pt)
+        return round(statistics.median(ts) * 1e3, 3)
+
     def lone_resident(k):
         dp, ds = cfg.alloc(64 * k), cfg.alloc(32 * k)
         cfg.to_device(dp, h_pts[0][:64 * k])
@@ -432,12 +448,18 @@ def drop_in_caller_figures(m, cfg, h_sc, h_pts, n, inst, expect):
 
     res["single_call_ms"] = {"msm_best_host_2^20": lone_best(min(n, 1 << 20)),
                              "gpu_msm_h2c_host_2^20": lone(min(n, 1 << 20)),
+                             "gpu_msm_h2c_host_registered_2^20": lone_registered(min(n, 1 << 20)),
                              "gpu_msm_h2c_host_2^18": lone(min(n, 1 << 18)),
                              "resident_2^20": lone_resident(min(n, 1 << 20)),
                              "resident_2^18": lone_resident(min(n, 1 << 18)),
                              "note": "median wall time of ONE blocking call, nothing else in flight; msm_best = the "
                                      "entry point the reference's criterion bench calls per instance "
-                                     "(benches/msm_benchmark.rs:116-121): zero-scalar filter on the device + MSM"}
+                                     "(benches/msm_benchmark.rs:116-121): zero-scalar filter on the device + MSM.  "
+                                     "Host calls of 2^19 points or more run as pipelined point ranges when the upload "
+                                     "can overlap kernels: always for page-locked slices; for pageable slices only on a "
+                                     "HIP >= 7.2 runtime -- this process is bound to the HIP 7.0 runtime of the PyTorch "
+                                     "wheel, whose pageable copies serialise (profiles/r02_lone_call_split.txt: "
+                                     "3.1 ms pageable on the system runtime)"}
     return res
 
 

@@ -806,15 +806,47 @@ int wait_batch(msm_amd_ctx* ctx, int ticket) {
 // (and, from host buffers, the upload) of range k + 1 overlaps the accumulate kernel of range k.  Costs: one window
 // reduction and one host Horner pass per range (overlapped, except the last) and a final addition of `parts` points.
 // Thresholds measured on MI355X (profiles/r02_lone_call_split.txt); MSM_AMD_SPLIT=<parts> forces a count, 1 disables.
-unsigned split_parts(const msm_amd_ctx* ctx, int point_layout, size_t n, bool host_buffers) {
+// Is this host pointer page-locked (msm_amd_host_register, hipHostMalloc, hipHostRegister)?
+bool host_pinned(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
+// Pageable uploads of one range overlap the kernels of the previous range only if the runtime's staged copy does not
+// serialise with the device.  Measured on this image: the system runtime (HIP 7.2) overlaps them (2^22 host points:
+// 14.0 -> 9.6 ms with 4 ranges); the HIP 7.0 runtime bundled with the PyTorch wheel -- which the process binds to when
+// torch is imported first, as in bench.py -- does not (14.0 -> 14.9 ms).  Page-locked buffers overlap on both.
+bool pageable_uploads_overlap() {
+  static const bool ok = [] {
+    int v = 0;
+    if (hipRuntimeGetVersion(&v) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    return v >= 70200000;
+  }();
+  return ok;
+}
+
+unsigned split_parts(const msm_amd_ctx* ctx, int point_layout, size_t n, bool host_buffers, const void* scalars = nullptr,
+                     const void* points = nullptr) {
   if (point_layout == MSM_AMD_POINT_TABLES || !lone_call(ctx, 1)) return 1;
   unsigned parts = 1;
   if (const char* e = std::getenv("MSM_AMD_SPLIT")) {
     parts = (unsigned)std::max(1, std::min(8, std::atoi(e)));
   } else {
     const uint32_t l = floor_log2(n);
-    if (host_buffers) parts = l >= 22 ? 8 : (l >= 20 ? 4 : (l >= 19 ? 2 : 1));   // the upload overlaps too
-    else parts = l >= 24 ? 8 : (l == 23 ? 4 : 1);
+    if (host_buffers) {   // the upload overlaps too
+      const bool dev_points = point_layout == MSM_AMD_POINT_PREPARED;
+      const bool pinned = scalars && host_pinned(scalars) && (dev_points || (points && host_pinned(points)));
+      if (pinned || pageable_uploads_overlap()) parts = l >= 22 ? 8 : (l >= 20 ? 4 : (l >= 19 ? 2 : 1));
+    } else {
+      parts = l >= 24 ? 8 : (l == 23 ? 4 : 1);
+    }
   }
   while (parts > 1 && n / parts < 4096) parts >>= 1;
   return parts;
@@ -890,7 +922,7 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
   const bool dev_points = point_layout == MSM_AMD_POINT_PREPARED || point_layout == MSM_AMD_POINT_TABLES;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n_inst == 1 && scalars[0] && points[0] && n[0]) {   // a lone call of many points: pipelined point ranges
-    const unsigned parts = split_parts(ctx, point_layout, n[0], true);
+    const unsigned parts = split_parts(ctx, point_layout, n[0], true, scalars[0], points[0]);
     if (parts > 1) return run_split(ctx, scalar_layout, point_layout, scalars[0], points[0], n[0], parts, out, true);
   }
   for (size_t i = 0; i < n_inst; ++i) {
