@@ -22,7 +22,7 @@
 //   reduce stream (k_accumulate.hip, k_reduce.hip)
 //   combine_small/big     sum the partials of split buckets into buckets
 //   sum_groups_kernel     buckets -> row sums R[W][2^H] and column sums C[W][2^L] of the slot matrix (slot = hi * 2^L
-//                         + lo), in log8 levels of groups of 8: plain sums, every bucket added exactly twice
+//                         + lo), in levels of groups of 16 (4..16 for a lone call): plain sums, every bucket added exactly twice
 //   reduce_bits_kernel    R, C -> partial[W][lb + 1]  (bit-subset sums of C and of R + the window total, external
 //                         Jacobian): window value = total + sum_k 2^k CB_k + 2^L sum_k 2^k RB_k
 //   host                  Horner over the bit positions of the (lb + 1) * W partial points (msm_host.hip host_combine)

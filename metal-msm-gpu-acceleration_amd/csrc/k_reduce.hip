@@ -5,7 +5,7 @@
 //     sum_i (i + 1) X[i] = sum_i X[i]  +  sum_lo lo * C[lo]  +  2^L * sum_hi hi * R[hi]
 //     R[hi] = sum_lo X[hi, lo]  (row sums)        C[lo] = sum_hi X[hi, lo]  (column sums)
 // Row and column sums are PLAIN sums: every bucket is added exactly twice, in independent chains of at most 7
-// additions (sum_groups_kernel, groups of 8, log8 levels), instead of the running-sum pair "sum += X; sos += sum"
+// additions (sum_groups_kernel, groups of 16 -- per level 4..16 for a lone call --), instead of the running-sum pair "sum += X; sos += sum"
 // (two dependent additions per bucket) followed by bit-subset tree sums over the segment sums (another 0.9 per
 // bucket) that round 1 used: 2.0 instead of 2.9 full additions per bucket, and chains half as long.  The weights
 // lo and hi are applied the same way as before: bit-subset sums over the 2^L column sums and the 2^H row sums
