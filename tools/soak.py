@@ -24,11 +24,12 @@ def main():
     cfg = m.setup_metal_state()
     rng = random.Random(a.seed)
     sizes = [1, 7, 33, 100, 1000, 4097, 1 << 14, 1 << 16, (1 << 17) + 3, 1 << 18]
-    pool = {}
+    pool, host = {}, {}
     for n in sizes:                                   # one resident instance per size, oracle answer cached
         dp, ds = cfg.generate_instance(o.SEED_BASE + 9000 + n, n, True)
         pb, sb = co.gen_instance(o.SEED_BASE + 9000 + n, n)
         pool[n] = (dp, ds, o.decode_jacobian_mont_le(co.msm_best(sb, pb, n)))
+        host[n] = (pb, sb)
     checked = 0
     for r in range(a.rounds):
         cfg.set_window_size(rng.choice([0, 0, 0, 5, 9, 13, 15, 16, 17]))
@@ -42,10 +43,18 @@ def main():
             for n, out in zip(pick, outs):
                 assert o.decode_jacobian_mont_le(out) == pool[n][2], (r, n)
                 checked += 1
-        if r % 3 == 0:                                # nothing in flight now: a LONE call (one stream, lone window policy)
-            n = rng.choice(sizes)
-            out = cfg.msm_batch_device([pool[n][1]], [pool[n][0]], [n])[0]
-            assert o.decode_jacobian_mont_le(out) == pool[n][2], ("lone", r, n)
+        if r % 3 == 0:                                # nothing in flight now: a LONE call (one stream, lone window policy),
+            n = rng.choice(sizes)                     # unsplit or forced into pipelined point ranges, device or host buffers
+            parts = rng.choice(["1", "2", "3", "4", "8"])
+            os.environ["MSM_AMD_SPLIT"] = parts
+            try:
+                if rng.random() < 0.5:
+                    out = cfg.msm_batch_device([pool[n][1]], [pool[n][0]], [n])[0]
+                else:
+                    out = m.gpu_msm_h2c(host[n][1], host[n][0], cfg)
+            finally:
+                del os.environ["MSM_AMD_SPLIT"]
+            assert o.decode_jacobian_mont_le(out) == pool[n][2], ("lone", r, n, parts)
             checked += 1
     cfg.set_window_size(0)
     print(f"soak ok: {a.rounds} rounds, {checked} MSMs checked against the oracle")
