@@ -800,12 +800,6 @@ int wait_batch(msm_amd_ctx* ctx, int ticket) {
   return MSM_AMD_OK;
 }
 
-// A LONE call of many points runs as ONE PIPELINED BATCH of sub-instances over point ranges (the algebra of the
-// reference's GPU + CPU split, msm.rs:385-419: the MSM of a union of point ranges is the sum of the MSMs).  Alone, an
-// instance is a serial chain upload -> conversion / digits / sort -> accumulate -> reduction; as a batch, the front end
-// (and, from host buffers, the upload) of range k + 1 overlaps the accumulate kernel of range k.  Costs: one window
-// reduction and one host Horner pass per range (overlapped, except the last) and a final addition of `parts` points.
-// Thresholds measured on MI355X (profiles/r02_lone_call_split.txt); MSM_AMD_SPLIT=<parts> forces a count, 1 disables.
 // Is this host pointer page-locked (msm_amd_host_register, hipHostMalloc, hipHostRegister)?
 bool host_pinned(const void* p) {
   hipPointerAttribute_t attr;
@@ -832,6 +826,12 @@ bool pageable_uploads_overlap() {
   return ok;
 }
 
+// A LONE call of many points runs as ONE PIPELINED BATCH of sub-instances over point ranges (the algebra of the
+// reference's GPU + CPU split, msm.rs:385-419: the MSM of a union of point ranges is the sum of the MSMs).  Alone, an
+// instance is a serial chain upload -> conversion / digits / sort -> accumulate -> reduction; as a batch, the front end
+// (and, from host buffers, the upload) of range k + 1 overlaps the accumulate kernel of range k.  Costs: one window
+// reduction and one host Horner pass per range (overlapped, except the last) and a final addition of `parts` points.
+// Thresholds measured on MI355X (profiles/r02_lone_call_split.txt); MSM_AMD_SPLIT=<parts> forces a count, 1 disables.
 unsigned split_parts(const msm_amd_ctx* ctx, int point_layout, size_t n, bool host_buffers, const void* scalars = nullptr,
                      const void* points = nullptr) {
   if (point_layout == MSM_AMD_POINT_TABLES || !lone_call(ctx, 1)) return 1;
