@@ -9,8 +9,9 @@
  *   - plain pointers and sizes only; no C++ or torch types;
  *   - every function returns an int status (0 = OK), never aborts;
  *   - a ctx owns one HIP device, four HIP streams (front end, accumulate, two reduce streams: consecutive
- *     instances overlap their phases) and grow-on-demand device workspaces; calls on one ctx are serialised
- *     internally, different ctxs (one per GPU) run concurrently;
+ *     instances overlap their phases) plus a copy stream, and grow-on-demand device workspaces; calls on one ctx are
+ *     serialised internally, different ctxs (one per GPU, or several on one GPU) run concurrently -- see
+ *     msm_amd_msm_batch_multi;
  *   - all 256-bit values are little-endian (least significant byte first) unless a *_BE32 layout
  *     is named; field coordinates are in Montgomery form with R = 2^256 exactly as halo2curves and
  *     arkworks hold them in memory.
@@ -149,6 +150,20 @@ int msm_amd_msm_batch(msm_amd_ctx* ctx, int scalar_layout, int point_layout, siz
 int msm_amd_host_register(msm_amd_ctx* ctx, const void* ptr, size_t bytes);
 int msm_amd_host_unregister(msm_amd_ctx* ctx, const void* ptr);
 
+/* Resident-bases speed for drop-in callers, without an API change (opt-in).  The reference's callers hand over the
+ * SAME bases slice on every call (benches/msm_benchmark.rs:116-121) and the reference re-uploads and re-converts it
+ * every time (msm.rs:152-153).  With a cache budget of max_bytes > 0 (or MSM_AMD_BASES_CACHE_MB at msm_amd_init) the
+ * host-slice entry points -- msm_amd_gpu_msm_h2c, msm_amd_msm, msm_amd_msm_batch, msm_amd_metal_msm_ark,
+ * msm_amd_msm_best -- keep the converted device copy of every points array they see (64 B per point, least recently
+ * used arrays make way) and on the next call with the same (pointer, n, layout) upload the scalars only.
+ * Contract: an array handed over at an unchanged address holds unchanged bases.  As a safety net every hit re-hashes
+ * ~2 k sampled records of the caller's memory (record i belongs to phase i mod (n / 1024); phase 0 and one rotating
+ * phase are checked per call): a changed array is detected at once if the change touches phase 0, within n / 1024
+ * calls otherwise, and is then re-uploaded.  max_bytes = 0 switches the cache off and frees it.
+ * stats: [0] hits, [1] misses (entries filled), [2] invalidations (checksum mismatch), [3] bytes held, [4] entries. */
+int msm_amd_set_bases_cache(msm_amd_ctx* ctx, size_t max_bytes);
+int msm_amd_bases_cache_stats(msm_amd_ctx* ctx, uint64_t stats[5]);
+
 /* ---- hybrid front-end ----------------------------------------------------------------------- */
 /* msm_best::<G1Affine, ..>(scalars, points) -> G1 (msm.rs:424-445): filter_zeros (drop zero scalars when at
  * least 30 % of them are zero, msm.rs:448-507, done here by a device compaction) and then the MSM.  The
@@ -167,6 +182,17 @@ int msm_amd_gpu_with_cpu(msm_amd_ctx* ctx, const void* scalars, const void* poin
 /* The reference's split policy (msm.rs:377-383): n/3 below 2^18, n/2 below 2^20, else 2n/3 go to the GPU.
  * On MI355X the throughput-optimal split is split_at = n; the policy is kept for parity. */
 size_t msm_amd_reference_split(size_t n);
+/* The split measured on MI355X: the whole instance goes to the GPU (split_at = n) unless it is smaller than
+ * msm_amd_cpu_dispatch_below() -- a CPU share only lengthens the call on this hardware. */
+size_t msm_amd_tuned_split(size_t n);
+/* The CPU MSM of the library by itself (no ctx, no GPU): what `gpu_profiler <log> <n> cpu` runs where the reference
+ * runs halo2curves::msm::msm_best (gpu_profiler.rs:157-159).  Multi-threaded signed-digit Pippenger with
+ * batched-affine bucket additions on 4 x 64-bit limbs; h2c affine points, scalars MONT_LE or CANON_LE;
+ * threads <= 0: msm_amd_host_threads().  out96 as every other entry point (normalised Jacobian). */
+int msm_amd_host_msm(int scalar_layout, int point_layout, const void* scalars, const void* points, size_t n, int threads,
+                     void* out96);
+/* CPUs the process may really use: affinity mask capped by the cgroup CPU quota. */
+int msm_amd_host_threads(void);
 
 /* ---- whole-MSM entry points: inputs already resident in device memory ------------------------ */
 /* Same as msm_amd_msm / msm_amd_msm_batch but scalars/points are device pointers on ctx's device
@@ -185,6 +211,49 @@ int msm_amd_submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_l
                                 const void* const* d_scalars, const void* const* d_points, const size_t* n,
                                 void* out_host, int* ticket);
 int msm_amd_wait_batch(msm_amd_ctx* ctx, int ticket);
+
+/* Upper bound of every host wait for the GPU inside the library, in milliseconds (default 60 000, or the environment
+ * variable MSM_AMD_WAIT_TIMEOUT_MS at msm_amd_init; 0 = wait without bound).  The reference's gpu_msm_h2c_sync is one
+ * blocking call that always returns (msm.rs:237-349); so is every call here: a wait that reaches the bound returns
+ * MSM_AMD_PIPELINE_ERROR and msm_amd_last_error names the stage event and the instance the device did not reach.
+ * The work stays in flight: a ticket of msm_amd_submit_batch_device stays valid and may be waited for again; after a
+ * blocking entry point timed out, the next call first checks whether the device has caught up (and fails the same
+ * way if not); msm_amd_synchronize waits once more; msm_amd_destroy gives the device resources up rather than
+ * freeing memory under running kernels. */
+int msm_amd_set_wait_timeout_ms(msm_amd_ctx* ctx, uint32_t timeout_ms);
+
+/* ---- several GPUs ---------------------------------------------------------
+ * The instance loop of the reference (gpu_profiler.rs:101-106, benches/msm_benchmark.rs:29-34) sharded over
+ * several ctxs: instance j runs on ctxs[j mod n_ctx], one host thread per ctx (pinned to the CPUs local to the
+ * ctx's GPU when sysfs exposes them), no data-path collective; results land at out + 96 j.  The ctxs may sit on
+ * different GPUs (the intended use) or on one (they then share it).  _multi takes host buffers like
+ * msm_amd_msm_batch; _multi_device takes device buffers, those of instance j on the device of ctxs[j mod n_ctx].
+ * On failure the first failing ctx's status is returned and msm_amd_last_error(that ctx) has the detail. */
+int msm_amd_msm_batch_multi(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout, size_t n_inst,
+                            const void* const* scalars, const void* const* points, const size_t* n, void* out);
+int msm_amd_msm_batch_multi_device(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout,
+                                   size_t n_inst, const void* const* d_scalars, const void* const* d_points,
+                                   const size_t* n, void* out_host);
+/* The sharding arithmetic: owner of instance j, and how many instances ctx k of n_ctx gets. */
+size_t msm_amd_shard_owner(size_t instance, size_t n_ctx);
+size_t msm_amd_shard_count(size_t n_inst, size_t n_ctx, size_t k);
+/* HIP device ordinal of a ctx. */
+int msm_amd_ctx_device(const msm_amd_ctx* ctx);
+/* Restrict the calling thread to the CPUs local to `device` (sysfs local_cpulist of its PCI function, intersected
+ * with the thread's current mask).  0 = pinned, 1 = no NUMA information or nothing to intersect (not an error). */
+int msm_amd_pin_thread_to_device(int device);
+
+/* RCCL all-gather of per-rank result blocks (one communicator per listed device, created in this process with
+ * ncclCommInitAll; librccl is loaded on first use, not linked).  send_host[k] = rank k's bytes_per_rank bytes
+ * (its ceil(I / G) x 96 B of results), recv_host[k] = n_devices x bytes_per_rank bytes, every rank's block in rank
+ * order, moved through rank k's GPU over xGMI.  A deployment with one PROCESS per GPU does the same with its own
+ * communicator (bench.py: torch.distributed, backend nccl = RCCL). */
+typedef struct msm_amd_gather msm_amd_gather;
+int msm_amd_gather_init(const int* devices, int n_devices, msm_amd_gather** out);
+int msm_amd_gather_size(const msm_amd_gather* g);
+int msm_amd_gather_all(msm_amd_gather* g, const void* const* send_host, size_t bytes_per_rank, void* const* recv_host);
+const char* msm_amd_gather_last_error(const msm_amd_gather* g);
+void msm_amd_gather_destroy(msm_amd_gather* g);
 
 /* ---- persistent bases -----------------------------------------------------------------------
  * The reference converts and re-uploads the bases on every call (msm.rs:152-153); provers reuse one SRS for
@@ -235,6 +304,9 @@ int msm_amd_synchronize(msm_amd_ctx* ctx);
  * G1 points (64 B affine, Montgomery) and n uniform scalars (Montgomery if scalars_mont else canonical LE). */
 int msm_amd_generate_instance(msm_amd_ctx* ctx, uint64_t seed, size_t n, int scalars_mont, void* d_points,
                               void* d_scalars);
+
+/* The same instance generated on the host (identical bytes; no ctx, no GPU): inputs of `gpu_profiler ... cpu`. */
+int msm_amd_generate_instance_host(uint64_t seed, size_t n, int scalars_mont, void* points, void* scalars, int threads);
 
 /* ---- instance files (src/utils/preprocess.rs:30-111, 143-212) -------------------------------------
  * The reference caches benchmark inputs as bincode 1.3 `Vec<(Vec<Vec<u32>>, Vec<Vec<u32>>)>`:
@@ -341,6 +413,11 @@ enum {
 int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count);
 /* The same operation bodies executed on the host CPU (no GPU needed): host-logic tests. */
 int msm_amd_test_op_host(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count);
+
+/* Test aid for the bounded waits: keeps the ctx's main stream busy for at most max_ms (<= 5000) or until
+ * msm_amd_test_release(handle).  The kernel carries its own time limit. */
+int msm_amd_test_hold(msm_amd_ctx* ctx, uint32_t max_ms, void** handle);
+int msm_amd_test_release(msm_amd_ctx* ctx, void* handle);
 
 /* ---- introspection --------------------------------------------------------------------------- */
 int msm_amd_last_timings(const msm_amd_ctx* ctx, msm_amd_timings* out);

@@ -48,6 +48,11 @@ EXPORTS = [
     "msm_amd_from_wire", "msm_amd_sort_pairs_device", "msm_amd_bases_upload", "msm_amd_bases_prepare_device",
     "msm_amd_msm_prepared", "msm_amd_sum_points", "msm_amd_tables_build", "msm_amd_tables_build_device",
     "msm_amd_tables_info", "msm_amd_tables_free", "msm_amd_msm_tables",
+    "msm_amd_set_wait_timeout_ms", "msm_amd_set_bases_cache", "msm_amd_bases_cache_stats", "msm_amd_test_hold",
+    "msm_amd_test_release", "msm_amd_msm_batch_multi", "msm_amd_msm_batch_multi_device", "msm_amd_shard_owner",
+    "msm_amd_shard_count", "msm_amd_ctx_device", "msm_amd_pin_thread_to_device", "msm_amd_gather_init",
+    "msm_amd_gather_size", "msm_amd_gather_all", "msm_amd_gather_last_error", "msm_amd_gather_destroy",
+    "msm_amd_host_msm", "msm_amd_tuned_split", "msm_amd_host_threads", "msm_amd_generate_instance_host",
 ]
 
 
@@ -157,6 +162,31 @@ def _lib():
         L.msm_amd_last_timings.argtypes = [c_void_p, POINTER(Timings)]
         L.msm_amd_algorithmic_bytes.argtypes = [c_size_t, c_uint32, c_int]
         L.msm_amd_algorithmic_bytes.restype = c_uint64
+        L.msm_amd_set_wait_timeout_ms.argtypes = [c_void_p, c_uint32]
+        L.msm_amd_set_bases_cache.argtypes = [c_void_p, c_size_t]
+        L.msm_amd_bases_cache_stats.argtypes = [c_void_p, POINTER(c_uint64)]
+        L.msm_amd_test_hold.argtypes = [c_void_p, c_uint32, POINTER(c_void_p)]
+        L.msm_amd_test_release.argtypes = [c_void_p, c_void_p]
+        L.msm_amd_msm_batch_multi.argtypes = [POINTER(c_void_p), c_size_t, c_int, c_int, c_size_t, POINTER(c_void_p),
+                                              POINTER(c_void_p), POINTER(c_size_t), c_void_p]
+        L.msm_amd_msm_batch_multi_device.argtypes = L.msm_amd_msm_batch_multi.argtypes
+        L.msm_amd_shard_owner.argtypes = [c_size_t, c_size_t]
+        L.msm_amd_shard_owner.restype = c_size_t
+        L.msm_amd_shard_count.argtypes = [c_size_t, c_size_t, c_size_t]
+        L.msm_amd_shard_count.restype = c_size_t
+        L.msm_amd_ctx_device.argtypes = [c_void_p]
+        L.msm_amd_pin_thread_to_device.argtypes = [c_int]
+        L.msm_amd_gather_init.argtypes = [POINTER(c_int), c_int, POINTER(c_void_p)]
+        L.msm_amd_gather_size.argtypes = [c_void_p]
+        L.msm_amd_gather_all.argtypes = [c_void_p, POINTER(c_void_p), c_size_t, POINTER(c_void_p)]
+        L.msm_amd_gather_last_error.argtypes = [c_void_p]
+        L.msm_amd_gather_last_error.restype = c_char_p
+        L.msm_amd_gather_destroy.argtypes = [c_void_p]
+        L.msm_amd_gather_destroy.restype = None
+        L.msm_amd_host_msm.argtypes = [c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+        L.msm_amd_generate_instance_host.argtypes = [c_uint64, c_size_t, c_int, c_void_p, c_void_p, c_int]
+        L.msm_amd_tuned_split.argtypes = [c_size_t]
+        L.msm_amd_tuned_split.restype = c_size_t
         _LIB = L
     return _LIB
 
@@ -249,6 +279,30 @@ class MsmConfig:
         ticket, out, k = handle
         self._check(_lib().msm_amd_wait_batch(self.h, ticket))
         return [out.raw[96 * i:96 * i + 96] for i in range(k)]
+
+    def set_wait_timeout_ms(self, ms: int):
+        """Upper bound of every host wait for the GPU (0 = none); a wait that reaches it raises PIPELINE_ERROR."""
+        self._check(_lib().msm_amd_set_wait_timeout_ms(self.h, ms))
+
+    def set_bases_cache(self, max_bytes: int):
+        """Opt-in cache of converted bases for the host-slice entry points (0 = off)."""
+        self._check(_lib().msm_amd_set_bases_cache(self.h, max_bytes))
+
+    def bases_cache_stats(self):
+        st = (c_uint64 * 5)()
+        self._check(_lib().msm_amd_bases_cache_stats(self.h, st))
+        return {"hits": st[0], "misses": st[1], "invalidations": st[2], "bytes": st[3], "entries": st[4]}
+
+    def test_hold(self, max_ms: int):
+        h = c_void_p()
+        self._check(_lib().msm_amd_test_hold(self.h, max_ms, ctypes.byref(h)))
+        return h
+
+    def test_release(self, handle):
+        self._check(_lib().msm_amd_test_release(self.h, handle))
+
+    def device(self) -> int:
+        return _lib().msm_amd_ctx_device(self.h)
 
     def host_register(self, data: bytes):
         """Page-lock the memory of a bytes object (keep it alive until host_unregister): DMA uploads."""
@@ -375,6 +429,85 @@ class MsmConfig:
         out = (c_uint32 * (count * per))()
         self._check(_lib().msm_amd_test_op(self.h, op, _u32buf(a), _u32buf(b), out, count))
         return list(out)
+
+
+def msm_batch_multi(configs, scalars_list, points_list, ns, scalar_layout=SCALAR_MONT_LE,
+                    point_layout=POINT_H2C_AFFINE, device=False):
+    """The instance loop sharded over several configs (gpu_profiler.rs:101-106): instance j -> configs[j mod G], one
+    host thread per config inside the library.  device=True: lists of device pointers (instance j on config j mod G's
+    GPU)."""
+    k, g = len(ns), len(configs)
+    cc = (c_void_p * g)(*[c.h for c in configs])
+    if device:
+        sp = (c_void_p * k)(*scalars_list)
+        pp = (c_void_p * k)(*points_list)
+    else:
+        sp = (c_void_p * k)(*[ctypes.cast(ctypes.c_char_p(s), c_void_p) for s in scalars_list])
+        pp = (c_void_p * k)(*[ctypes.cast(ctypes.c_char_p(p), c_void_p) for p in points_list])
+    nn = (c_size_t * k)(*ns)
+    out = ctypes.create_string_buffer(96 * k)
+    fn = _lib().msm_amd_msm_batch_multi_device if device else _lib().msm_amd_msm_batch_multi
+    st = fn(cc, g, scalar_layout, point_layout, k, sp, pp, nn, out)
+    if st != OK:
+        detail = "; ".join(_lib().msm_amd_last_error(c.h).decode() for c in configs)
+        raise MsmError(st, detail)
+    return [out.raw[96 * i:96 * i + 96] for i in range(k)]
+
+
+def shard_owner(instance: int, n_ctx: int) -> int:
+    return _lib().msm_amd_shard_owner(instance, n_ctx)
+
+
+def shard_count(n_inst: int, n_ctx: int, k: int) -> int:
+    return _lib().msm_amd_shard_count(n_inst, n_ctx, k)
+
+
+class RcclGather:
+    """RCCL all-gather of per-rank result blocks from C++ (msm_amd_gather_*): one communicator per listed device."""
+
+    def __init__(self, devices):
+        self.g = c_void_p()
+        arr = (c_int * len(devices))(*devices)
+        st = _lib().msm_amd_gather_init(arr, len(devices), ctypes.byref(self.g))
+        if st != OK:
+            raise MsmError(st, "msm_amd_gather_init")
+        self.n = len(devices)
+
+    def all_gather(self, blocks):
+        per = len(blocks[0])
+        send = (c_void_p * self.n)(*[ctypes.cast(ctypes.c_char_p(b), c_void_p) for b in blocks])
+        outs = [ctypes.create_string_buffer(per * self.n) for _ in range(self.n)]
+        recv = (c_void_p * self.n)(*[ctypes.cast(o, c_void_p) for o in outs])
+        st = _lib().msm_amd_gather_all(self.g, send, per, recv)
+        if st != OK:
+            raise MsmError(st, _lib().msm_amd_gather_last_error(self.g).decode())
+        return [o.raw for o in outs]
+
+    def close(self):
+        if self.g:
+            _lib().msm_amd_gather_destroy(self.g)
+        self.g = None
+
+
+def host_msm(scalars: bytes, points: bytes, n: int, threads=0, scalar_layout=SCALAR_MONT_LE,
+             point_layout=POINT_H2C_AFFINE) -> bytes:
+    """The product's CPU MSM (where the reference calls halo2curves::msm::msm_best: gpu_profiler.rs:157-159,
+    msm.rs:412) -- host code of the library, no GPU and no ctx needed."""
+    out = ctypes.create_string_buffer(96)
+    st = _lib().msm_amd_host_msm(scalar_layout, point_layout, scalars, points, n, threads, out)
+    if st != OK:
+        raise MsmError(st)
+    return out.raw
+
+
+def generate_instance_host(seed, n, scalars_mont=True, threads=0):
+    """(points, scalars) of the deterministic synthetic instance, generated on the host by the library."""
+    pts = ctypes.create_string_buffer(64 * n)
+    sc = ctypes.create_string_buffer(32 * n)
+    st = _lib().msm_amd_generate_instance_host(seed, n, 1 if scalars_mont else 0, pts, sc, threads)
+    if st != OK:
+        raise MsmError(st)
+    return pts.raw, sc.raw
 
 
 def test_op_host(op, a, b, count):

@@ -111,7 +111,7 @@ inline Fe sub(const Fe& a, const Fe& b) {
     t2 = (uint64_t)c;                                       \
     t3 = t4 + (uint64_t)(c >> 64);                          \
   }
-inline Fe mul(const Fe& a, const Fe& b) {
+inline Fe mul_portable(const Fe& a, const Fe& b) {
   uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
   MSM_H64_ROUND(b.v[0])
   MSM_H64_ROUND(b.v[1])
@@ -126,6 +126,50 @@ inline Fe mul(const Fe& a, const Fe& b) {
   return r;
 }
 #undef MSM_H64_ROUND
+
+#if defined(__x86_64__) && defined(__BMI2__) && defined(__ADX__) && !defined(MSM_H64_NO_ASM)
+// The same CIOS rounds with MULX and the two independent carry chains of ADCX (CF) / ADOX (OF): the low halves of
+// a_j * b_i ride one chain, the high halves the other, so no carry is ever materialised in a register.  The
+// running value lives in five registers whose roles rotate from round to round (the word that the reduction zeroes
+// becomes the next round's top word).  ~1.45x the rate of the portable form above on Zen 5 / Sapphire Rapids;
+// built only where the compiler is told the host has BMI2 + ADX (csrc/Makefile: HOST64_FLAGS).
+#define MSM_H64_ASM_ROUND(i, T0, T1, T2, T3, T4)                                                    \
+  "movq " #i "*8(%[b]), %%rdx\n\t"                                                                  \
+  "xorl %k[" #T4 "], %k[" #T4 "]\n\t" /* top word = 0; clears CF and OF */                           \
+  "mulx 0(%[a]), %[lo], %[hi]\n\t  adcx %[lo], %[" #T0 "]\n\t  adox %[hi], %[" #T1 "]\n\t"          \
+  "mulx 8(%[a]), %[lo], %[hi]\n\t  adcx %[lo], %[" #T1 "]\n\t  adox %[hi], %[" #T2 "]\n\t"          \
+  "mulx 16(%[a]), %[lo], %[hi]\n\t adcx %[lo], %[" #T2 "]\n\t  adox %[hi], %[" #T3 "]\n\t"          \
+  "mulx 24(%[a]), %[lo], %[hi]\n\t adcx %[lo], %[" #T3 "]\n\t  adox %[hi], %[" #T4 "]\n\t"          \
+  "movl $0, %k[lo]\n\t             adcx %[lo], %[" #T4 "]\n\t"                                      \
+  "movq %[" #T0 "], %%rdx\n\t      imulq %[ninv], %%rdx\n\t"                                        \
+  "xorl %k[hi], %k[hi]\n\t" /* clears CF and OF again (imul set them) */                            \
+  "mulx 0(%[p]), %[lo], %[hi]\n\t  adcx %[lo], %[" #T0 "]\n\t  adox %[hi], %[" #T1 "]\n\t"          \
+  "mulx 8(%[p]), %[lo], %[hi]\n\t  adcx %[lo], %[" #T1 "]\n\t  adox %[hi], %[" #T2 "]\n\t"          \
+  "mulx 16(%[p]), %[lo], %[hi]\n\t adcx %[lo], %[" #T2 "]\n\t  adox %[hi], %[" #T3 "]\n\t"          \
+  "mulx 24(%[p]), %[lo], %[hi]\n\t adcx %[lo], %[" #T3 "]\n\t  adox %[hi], %[" #T4 "]\n\t"          \
+  "movl $0, %k[lo]\n\t             adcx %[lo], %[" #T4 "]\n\t"
+inline Fe mul(const Fe& a, const Fe& b) {
+  static const uint64_t kP[4] = {P[0], P[1], P[2], P[3]};
+  uint64_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, lo, hi;
+  __asm__(MSM_H64_ASM_ROUND(0, r0, r1, r2, r3, r4)   /* leaves the value in r1 r2 r3 r4 (r0 = 0) */
+          MSM_H64_ASM_ROUND(1, r1, r2, r3, r4, r0)
+          MSM_H64_ASM_ROUND(2, r2, r3, r4, r0, r1)
+          MSM_H64_ASM_ROUND(3, r3, r4, r0, r1, r2)   /* result: r4 r0 r1 r2 */
+          : [r0] "+&r"(r0), [r1] "+&r"(r1), [r2] "+&r"(r2), [r3] "+&r"(r3), [r4] "+&r"(r4), [lo] "=&r"(lo), [hi] "=&r"(hi)
+          : [a] "r"(a.v), [b] "r"(b.v), [p] "r"(kP), [ninv] "r"(NINV), "m"(a), "m"(b), "m"(kP)
+          : "rdx", "cc");
+  Fe r;
+  r.v[0] = r4;
+  r.v[1] = r0;
+  r.v[2] = r1;
+  r.v[3] = r2;
+  reduce_once(r.v);
+  return r;
+}
+#undef MSM_H64_ASM_ROUND
+#else
+inline Fe mul(const Fe& a, const Fe& b) { return mul_portable(a, b); }
+#endif
 inline Fe sqr(const Fe& a) { return mul(a, a); }
 
 inline Fe one() {   // 2^256 mod p

@@ -1,102 +1,524 @@
-// Host-CPU bucket-method MSM used ONLY as the CPU half of gpu_with_cpu (src/metal/msm.rs:366-421), where the
-// reference calls the third-party halo2curves::msm::msm_best on its share of the points (msm.rs:412).  This is
-// product code (it ships in libmsm_amd.so); it is not the test oracle and the GPU path never routes through it.
-// Multi-threaded over point slices: every worker runs a serial signed-digit bucket method on its slice
-// (window c = ln(n) rounded up), the slice results are added.  Field arithmetic: bn254_fq.hip.h's host path
-// (4 x 64-bit limbs, unsigned __int128).
+// The product's CPU MSM: where the reference calls the third-party halo2curves::msm::msm_best -- the `cpu` mode of
+// gpu_profiler (src/bin/gpu_profiler.rs:157-159, BASELINE config 1), the CPU half of gpu_with_cpu
+// (src/metal/msm.rs:412) and msm_best's size dispatch (msm.rs:440-444).  Product code: it ships in libmsm_amd.so, it is
+// not the test oracle (nothing here includes or links oracle/), and the GPU entry points never route through it.
+//
+// Algorithm (written for this library, on the 4 x 64-bit host arithmetic of host_fq64.h):
+//   phase 0  scalars -> canonical -> signed c-bit digits, [window][point] int16, threads over point ranges
+//   phase 1  tasks (window, bucket range) with disjoint bucket sets: every task scans the window's digits and takes
+//            the points of its range; affine buckets are filled by BATCHED-AFFINE additions -- up to 512 pending
+//            (bucket, point) pairs with distinct buckets share one field inversion (Montgomery's trick, four
+//            interleaved product chains), ~8 field multiplications per addition instead of 11 for a Jacobian mixed
+//            addition; a point whose bucket is already pending in the batch goes to that bucket's Jacobian side
+//            accumulator instead (uniform scalars: a few per cent; all-equal scalars: all of them, still 11
+//            multiplications each -- no pathological case); the task then reduces its own buckets while they are in
+//            the cache: sum_b (b + 1) B_b = sum_range [ sum_{b in range} (b - lo + 1) B_b + lo * sum_{b in range} B_b ]
+//   phase 2  Horner over the windows (one thread; 254 doublings)
+// Tasks are handed out by an atomic counter; the team of threads lives for one call and meets at one spin barrier.
+// The window c minimises a cost model in field multiplications (window_for).
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
+#include "../../include/msm_amd.h"
+#include "device_common.hip.h"
 #include "launch.h"
+#include "host_fq64.h"
 
 namespace msm_amd {
 
 namespace {
 
-Affine affine_neg(const Affine& p) {
-  Affine r;
-  r.x = p.x;
-  r.y = Fq::neg(p.y);
+using h64::Fe;
+using h64::Jac;
+
+struct Aff {   // same 64 bytes as Affine: x, y Montgomery LE
+  Fe x, y;
+};
+static_assert(sizeof(Aff) == sizeof(Affine), "layout");
+
+inline bool fe_eq(const Fe& a, const Fe& b) {
+  return ((a.v[0] ^ b.v[0]) | (a.v[1] ^ b.v[1]) | (a.v[2] ^ b.v[2]) | (a.v[3] ^ b.v[3])) == 0;
+}
+inline Fe fe_neg(const Fe& a) {
+  Fe z;
+  std::memset(&z, 0, sizeof z);
+  return h64::is_zero(a) ? a : h64::sub(z, a);
+}
+
+// Jacobian + affine (finite), 8M + 3S, with the exceptional cases.
+inline Jac jmadd(const Jac& p, const Aff& q) {
+  if (h64::is_identity(p)) {
+    Jac r;
+    r.x = q.x;
+    r.y = q.y;
+    r.z = h64::one();
+    return r;
+  }
+  const Fe Z1Z1 = h64::sqr(p.z);
+  const Fe U2 = h64::mul(q.x, Z1Z1);
+  const Fe S2 = h64::mul(q.y, h64::mul(p.z, Z1Z1));
+  const Fe H = h64::sub(U2, p.x);
+  const Fe R = h64::sub(S2, p.y);
+  if (h64::is_zero(H)) {
+    if (h64::is_zero(R)) return h64::jdouble(p);
+    return h64::identity();
+  }
+  const Fe HH = h64::sqr(H);
+  const Fe HHH = h64::mul(H, HH);
+  const Fe V = h64::mul(p.x, HH);
+  Jac r;
+  r.x = h64::sub(h64::sub(h64::sqr(R), HHH), h64::dbl(V));
+  r.y = h64::sub(h64::mul(R, h64::sub(V, r.x)), h64::mul(p.y, HHH));
+  r.z = h64::mul(p.z, H);
   return r;
 }
 
-void msm_slice(const u256* scalars, int scalars_mont, const Affine* points, size_t n, Jacobian* out) {
-  Jacobian acc = jac_identity();
-  if (n == 0) {
-    *out = acc;
-    return;
+// k * p for a small k (the segment offset of phase 2), double-and-add from the top bit.
+inline Jac jmul_small(const Jac& p, uint32_t k) {
+  Jac acc = h64::identity();
+  for (int bit = 31; bit >= 0; --bit) {
+    acc = h64::jdouble(acc);
+    if ((k >> bit) & 1u) acc = h64::jadd(acc, p);
   }
-  uint32_t c = n < 32 ? 3u : (uint32_t)std::ceil(std::log((double)n));
-  c = std::min(16u, std::max(3u, c));
-  const uint32_t W = 254 / c + 1;
-  const uint32_t half = 1u << (c - 1);
-  std::vector<u256> ks(n);
-  for (size_t i = 0; i < n; ++i) {
-    if (scalars_mont) {
-      ks[i] = Fr::from_mont(scalars[i]);
-    } else {   // raw canonical integers may exceed r: reduce (2^256 / r < 6), as digits_kernel does
-      ks[i] = scalars[i];
-      for (int k = 0; k < 5; ++k) ks[i] = Fr::reduce_once(ks[i]);
+  return acc;
+}
+
+struct Barrier {   // the team meets here between phases; short waits, so spin (with yields) rather than sleep
+  explicit Barrier(int n) : total(n) {}
+  void wait() {
+    const int gen = generation.load(std::memory_order_acquire);
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == total) {
+      arrived.store(0, std::memory_order_relaxed);
+      generation.store(gen + 1, std::memory_order_release);
+      return;
     }
+    int spins = 0;
+    while (generation.load(std::memory_order_acquire) == gen)
+      if (++spins > 2000) std::this_thread::yield();
   }
-  // signed digits, window-major: digit[w][i]
-  std::vector<int32_t> digits((size_t)W * n);
-  for (size_t i = 0; i < n; ++i) {
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < W; ++w) {
-      const uint32_t start = w * c;
-      uint32_t v = (start < 256 ? u256_extract_bits(ks[i], start, c) : 0u) + carry;
-      carry = 0;
-      int32_t d = (int32_t)v;
-      if (v > half) {
-        d = (int32_t)v - (int32_t)(1u << c);
-        carry = 1;
+  const int total;
+  std::atomic<int> arrived{0}, generation{0};
+};
+
+// Buckets of one phase-1 task: affine value + occupancy + Jacobian side accumulator (z = 0: empty).
+struct BucketSet {
+  std::vector<Aff> aff;
+  std::vector<uint8_t> full;
+  std::vector<Jac> side;
+  std::vector<uint32_t> stamp;   // id of the batch in which the bucket has a pending addition
+  bool any_side = false;
+};
+
+constexpr int kBatch = 512;
+
+struct Pending {
+  uint32_t bucket[kBatch];
+  Aff pt[kBatch];
+  Fe den[kBatch], pre[kBatch];
+  uint8_t kind[kBatch];   // 0 = generic addition, 1 = doubling, 2 = P + (-P)
+  int count = 0;
+};
+
+// One shared inversion for the whole batch (Montgomery's trick), run as kLanes INTERLEAVED product chains (element k
+// belongs to chain k mod kLanes): a single chain is a string of dependent multiplications, i.e. bound by the LATENCY of
+// the field multiplication (~1.5x its reciprocal throughput); four independent chains keep the multiplier busy.
+constexpr int kLanes = 4;
+
+void flush(BucketSet& B, Pending& q) {
+  if (q.count == 0) return;
+  // denominators: x2 - x1, or 2 y for a doubling; one for P + (-P) so that the product stays invertible
+  for (int k = 0; k < q.count; ++k) {
+    const Aff& a = B.aff[q.bucket[k]];
+    Fe d = h64::sub(q.pt[k].x, a.x);
+    q.kind[k] = 0;
+    if (h64::is_zero(d)) {
+      if (fe_eq(q.pt[k].y, a.y)) {   // BN254 G1 has prime order: y != 0 for every finite point
+        q.kind[k] = 1;
+        d = h64::dbl(a.y);
+      } else {
+        q.kind[k] = 2;
+        d = h64::one();
       }
-      digits[(size_t)w * n + i] = d;
+    }
+    q.den[k] = d;
+    q.pre[k] = k >= kLanes ? h64::mul(q.pre[k - kLanes], d) : d;
+  }
+  // chain totals -> inverse of every chain total from ONE inversion
+  Fe tot[kLanes], inv[kLanes];
+  for (int j = 0; j < kLanes; ++j) {
+    if (j >= q.count) {
+      tot[j] = h64::one();
+      continue;
+    }
+    int last = q.count - 1;
+    last -= ((last - j) % kLanes + kLanes) % kLanes;   // largest k <= count - 1 with k mod kLanes == j
+    tot[j] = q.pre[last];
+  }
+  {
+    const Fe p01 = h64::mul(tot[0], tot[1]), p23 = h64::mul(tot[2], tot[3]);
+    const Fe all = h64::inv(h64::mul(p01, p23));
+    const Fe i01 = h64::mul(all, p23), i23 = h64::mul(all, p01);
+    inv[0] = h64::mul(i01, tot[1]);
+    inv[1] = h64::mul(i01, tot[0]);
+    inv[2] = h64::mul(i23, tot[3]);
+    inv[3] = h64::mul(i23, tot[2]);
+  }
+  for (int k = q.count - 1; k >= 0; --k) {
+    Fe& run = inv[k % kLanes];   // 1 / (product of this chain's denominators up to and including k)
+    const Fe dinv = k >= kLanes ? h64::mul(run, q.pre[k - kLanes]) : run;
+    if (k >= kLanes) run = h64::mul(run, q.den[k]);
+    Aff& a = B.aff[q.bucket[k]];
+    if (q.kind[k] == 2) {
+      B.full[q.bucket[k]] = 0;
+      continue;
+    }
+    Fe num;
+    if (q.kind[k] == 1) {
+      const Fe xx = h64::sqr(a.x);
+      num = h64::add(h64::dbl(xx), xx);
+    } else {
+      num = h64::sub(q.pt[k].y, a.y);
+    }
+    const Fe lambda = h64::mul(num, dinv);
+    const Fe x3 = h64::sub(h64::sub(h64::sqr(lambda), a.x), q.pt[k].x);
+    const Fe y3 = h64::sub(h64::mul(lambda, h64::sub(a.x, x3)), a.y);
+    a.x = x3;
+    a.y = y3;
+  }
+  q.count = 0;
+}
+
+// One task: window w, buckets [b_lo, b_hi).  Scans all n digits of the window (2 bytes per point) and takes the
+// points whose bucket falls into its range, so tasks own DISJOINT bucket sets: nothing to merge afterwards.
+// `batch` = pending additions per shared inversion; 0 = no batched-affine additions at all (every point goes to its
+// bucket's Jacobian accumulator): windows with few buckets or tasks with few points cannot fill a batch, and an
+// inversion costs ~380 multiplications.
+void fill_buckets(BucketSet& B, Pending& q, const int16_t* digits, const Aff* points, size_t p_lo, size_t p_hi,
+                  uint32_t b_lo, uint32_t b_hi, int batch) {
+  const uint32_t nbuckets = b_hi - b_lo;
+  B.aff.resize(nbuckets);
+  B.full.assign(nbuckets, 0);
+  B.stamp.assign(nbuckets, batch ? 0u : 1u);   // batch == 0: every bucket looks "pending" -> Jacobian path
+  B.side.clear();
+  B.any_side = false;
+  uint32_t batch_id = 1;
+  q.count = 0;
+  for (size_t i = p_lo; i < p_hi; ++i) {
+    const int32_t d = digits[i];
+    if (d == 0) continue;
+    const uint32_t slot = (uint32_t)(d < 0 ? -d : d) - 1;
+    if (slot < b_lo || slot >= b_hi) continue;
+    const Aff& src = points[i];
+    if (h64::is_zero(src.x) && h64::is_zero(src.y)) continue;   // affine identity (0, 0)
+    const uint32_t b = slot - b_lo;
+    Aff p = src;
+    if (d < 0) p.y = fe_neg(p.y);
+    if (B.stamp[b] == batch_id) {   // its bucket already has an addition pending in this batch
+      if (!B.any_side) {
+        B.side.resize(nbuckets);
+        std::memset((void*)B.side.data(), 0, nbuckets * sizeof(Jac));   // z = 0: identity
+        B.any_side = true;
+      }
+      B.side[b] = jmadd(B.side[b], p);
+      continue;
+    }
+    if (!B.full[b]) {
+      B.aff[b] = p;
+      B.full[b] = 1;
+      continue;
+    }
+    B.stamp[b] = batch_id;
+    q.bucket[q.count] = b;
+    q.pt[q.count] = p;
+    if (++q.count == batch) {
+      flush(B, q);
+      ++batch_id;
     }
   }
-  std::vector<Jacobian> buckets(half);
+  flush(B, q);
+}
+
+// sum_{b in [0, nb)} (b + 1) B_b of one task's buckets by running sums, as TWO interleaved chains (upper and lower
+// half of the range): a running sum is a string of dependent field multiplications, two independent ones in one loop
+// let the out-of-order core overlap them.  With m = nb / 2:
+//   sum = [ sum_{b >= m} (b - m + 1) B_b + m * sum_{b >= m} B_b ]  +  sum_{b < m} (b + 1) B_b
+// Also returns sum_b B_b (the caller adds b_lo times it for a task that does not start at bucket 0).
+void reduce_buckets(const BucketSet& B, uint32_t nb, Jac* weighted, Jac* plain) {
+  auto step = [&](uint32_t b, Jac& running, Jac& acc) {
+    if (B.full[b]) running = jmadd(running, B.aff[b]);
+    if (B.any_side && !h64::is_identity(B.side[b])) running = h64::jadd(running, B.side[b]);
+    acc = h64::jadd(acc, running);
+  };
+  const uint32_t m = nb / 2;
+  Jac run_hi = h64::identity(), acc_hi = h64::identity(), run_lo = h64::identity(), acc_lo = h64::identity();
+  for (uint32_t k = 0; k < m; ++k) {   // both halves top-down; the upper half has nb - m >= m buckets
+    step(nb - 1 - k, run_hi, acc_hi);
+    step(m - 1 - k, run_lo, acc_lo);
+  }
+  if ((nb - m) > m) step(m, run_hi, acc_hi);   // odd nb: the upper half's last bucket
+  Jac total = h64::jadd(acc_hi, acc_lo);
+  if (m) total = h64::jadd(total, jmul_small(run_hi, m));
+  *weighted = total;
+  *plain = h64::jadd(run_hi, run_lo);
+}
+
+// Cost model in field multiplications.  One addition into a bucket: Jacobian mixed addition 11; batched-affine 6 + its
+// share of the inversion (~384 / batch) + the collisions that fall back to the Jacobian accumulator (about
+// batch / (2 buckets) of the points, 11 each), with batch = a quarter of the task's buckets, at most kBatch.
+// Reduction per window and bucket: one mixed addition (11) and one full addition (16).
+struct Choice {
+  uint32_t c;
+  uint32_t ranges;   // bucket ranges (= tasks) per window
+  int batch;         // 0 = Jacobian accumulators only
+};
+int batch_for(uint32_t buckets_per_task, size_t points_per_task) {
+  const int batch = (int)std::min<size_t>(kBatch, buckets_per_task / 4);
+  if (batch < 8 || points_per_task < (size_t)4 * batch) return 0;
+  const double cost = 6.0 + 384.0 / batch + 11.0 * batch / (2.0 * buckets_per_task);
+  return cost < 11.0 ? batch : 0;
+}
+Choice window_for(size_t n, int threads) {
+  if (n < 32) return {3, 1, 0};   // the reference's policy for tiny instances (msm.rs:137-138)
+  Choice best{4, 1, 0};
+  double best_cost = 1e300;
+  for (uint32_t c = 4; c <= 15; ++c) {
+    const uint32_t W = 254 / c + 1, nb = 1u << (c - 1);
+    // about three tasks per thread, each with at least 32 buckets
+    uint32_t ranges = threads > 1 ? (uint32_t)((3 * threads + W - 1) / W) : 1u;
+    ranges = std::max(1u, std::min(ranges, nb / 32 ? nb / 32 : 1u));
+    const int batch = batch_for(nb / ranges, n / ranges);
+    const double add = batch ? 6.0 + 384.0 / batch + 11.0 * batch / (2.0 * (nb / ranges)) : 11.0;
+    // every task scans the window's n digits: ~0.05 multiplications' worth each
+    const double cost = (double)W * ((double)n * add + (double)nb * 27.0 + 0.05 * (double)n * ranges);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = {c, ranges, batch};
+    }
+  }
+  return best;
+}
+
+Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n, int threads) {
+  const int T = std::max(1, std::min<int>(threads, (int)std::min<size_t>((n + 63) / 64, 256)));
+  Choice choice = window_for(n, T);
+  if (const char* e = std::getenv("MSM_AMD_HOST_WINDOW")) {   // experiments
+    const int v = std::atoi(e);
+    if (v >= 3 && v <= 15) choice.c = (uint32_t)v;
+  }
+  if (const char* e = std::getenv("MSM_AMD_HOST_RANGES")) {
+    const int v = std::atoi(e);
+    if (v >= 1 && (uint32_t)v <= (1u << (choice.c - 1))) choice.ranges = (uint32_t)v;
+  }
+  if (std::getenv("MSM_AMD_HOST_WINDOW") || std::getenv("MSM_AMD_HOST_RANGES"))
+    choice.batch = batch_for((1u << (choice.c - 1)) / choice.ranges, n / choice.ranges);
+  const uint32_t c = choice.c, ranges = choice.ranges;
+  const uint32_t W = 254 / c + 1;
+  const uint32_t half = 1u << (c - 1);   // buckets per window: slot b <-> digit magnitude b + 1
+  const uint32_t range_len = (half + ranges - 1) / ranges;
+  std::vector<int16_t> digits((size_t)W * n);
+  std::vector<Jac> part((size_t)W * ranges);
+  std::atomic<size_t> next0{0}, next1{0}, next2{0};
+  const bool by_points = std::getenv("MSM_AMD_HOST_BY_POINTS") != nullptr;
+  std::vector<BucketSet> sets(by_points ? (size_t)W * ranges : 0);
+  Barrier barrier(T);
+  const size_t chunk0 = 1024;
+  const bool trace = std::getenv("MSM_AMD_HOST_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto stamp = [&](const char* what) {
+    if (trace)
+      std::fprintf(stderr, "host_msm: %-8s %8.3f ms (n=%zu c=%u W=%u ranges=%u batch=%d T=%d)\n", what,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), n, c, W,
+                   ranges, choice.batch, T);
+  };
+  auto worker = [&](int tid) {
+    // ---- phase 0: digits
+    for (;;) {
+      const size_t lo = next0.fetch_add(chunk0, std::memory_order_relaxed);
+      if (lo >= n) break;
+      const size_t hi = std::min(n, lo + chunk0);
+      for (size_t i = lo; i < hi; ++i) {
+        u256 k;
+        if (scalars_mont) {
+          k = Fr::from_mont(scalars[i]);
+        } else {   // raw canonical integers may exceed r: reduce (2^256 / r < 6), as digits_kernel does
+          k = scalars[i];
+          for (int t = 0; t < 5; ++t) k = Fr::reduce_once(k);
+        }
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < W; ++w) {
+          const uint32_t start = w * c;
+          const uint32_t v = (start < 256 ? u256_extract_bits(k, start, c) : 0u) + carry;
+          carry = 0;
+          int32_t d = (int32_t)v;
+          if (v > half) {
+            d = (int32_t)v - (int32_t)(1u << c);
+            carry = 1;
+          }
+          digits[(size_t)w * n + i] = (int16_t)d;
+        }
+      }
+    }
+    barrier.wait();
+    if (tid == 0) stamp("digits");
+    Pending* q = new Pending();
+    if (by_points) {   // EXPERIMENT: tasks (window, point group) with full bucket sets, merged in a second phase
+      for (;;) {
+        const size_t t = next1.fetch_add(1, std::memory_order_relaxed);
+        if (t >= (size_t)W * ranges) break;
+        const uint32_t w = (uint32_t)(t / ranges), g = (uint32_t)(t % ranges);
+        fill_buckets(sets[t], *q, &digits[(size_t)w * n], points, n * g / ranges, n * (g + 1) / ranges, 0, half, choice.batch);
+      }
+      barrier.wait();
+      for (;;) {
+        const size_t t = next2.fetch_add(1, std::memory_order_relaxed);
+        if (t >= (size_t)W * ranges) break;
+        const uint32_t w = (uint32_t)(t / ranges), sgm = (uint32_t)(t % ranges);
+        const uint32_t lo = std::min(half, sgm * range_len), hi = std::min(half, lo + range_len);
+        Jac running = h64::identity(), acc = h64::identity();
+        for (uint32_t b = hi; b-- > lo;) {
+          for (uint32_t g = 0; g < ranges; ++g) {
+            const BucketSet& S = sets[(size_t)w * ranges + g];
+            if (S.full[b]) running = jmadd(running, S.aff[b]);
+            if (S.any_side && !h64::is_identity(S.side[b])) running = h64::jadd(running, S.side[b]);
+          }
+          acc = h64::jadd(acc, running);
+        }
+        if (lo) acc = h64::jadd(acc, jmul_small(running, lo));
+        part[t] = acc;
+      }
+      delete q;
+      return;
+    }
+    // ---- phase 1: tasks (window, bucket range): fill the buckets, reduce them while they are hot in the cache
+    BucketSet* B = new BucketSet();
+    for (;;) {
+      const size_t t = next1.fetch_add(1, std::memory_order_relaxed);
+      if (t >= (size_t)W * ranges) break;
+      const uint32_t w = (uint32_t)(t / ranges), g = (uint32_t)(t % ranges);
+      const uint32_t b_lo = std::min(half, g * range_len), b_hi = std::min(half, b_lo + range_len);
+      if (b_lo == b_hi) {
+        part[t] = h64::identity();
+        continue;
+      }
+      fill_buckets(*B, *q, &digits[(size_t)w * n], points, 0, n, b_lo, b_hi, choice.batch);
+      Jac weighted, plain;
+      reduce_buckets(*B, b_hi - b_lo, &weighted, &plain);
+      if (b_lo) weighted = h64::jadd(weighted, jmul_small(plain, b_lo));
+      part[t] = weighted;
+    }
+    delete B;
+    delete q;
+  };
+  std::vector<std::thread> team;
+  for (int t = 1; t < T; ++t) team.emplace_back(worker, t);
+  worker(0);
+  for (std::thread& th : team) th.join();
+  stamp("buckets");
+  // ---- Horner over the windows (final_accumulation.rs:19-39)
+  Jac total = h64::identity();
   for (int w = (int)W - 1; w >= 0; --w) {
-    for (uint32_t i = 0; i < c; ++i) acc = jac_double(acc);
-    for (auto& b : buckets) b = jac_identity();
-    const int32_t* dw = &digits[(size_t)w * n];
-    for (size_t i = 0; i < n; ++i) {
-      const int32_t d = dw[i];
-      if (d == 0 || affine_is_identity(points[i])) continue;
-      const uint32_t m = (uint32_t)(d < 0 ? -d : d);
-      buckets[m - 1] = jac_madd(buckets[m - 1], d < 0 ? affine_neg(points[i]) : points[i]);
-    }
-    Jacobian run = jac_identity(), sum = jac_identity();
-    for (int b = (int)half - 1; b >= 0; --b) {
-      run = jac_add(run, buckets[b]);
-      sum = jac_add(sum, run);
-    }
-    acc = jac_add(acc, sum);
+    for (uint32_t i = 0; i < c; ++i) total = h64::jdouble(total);
+    for (uint32_t g = 0; g < ranges; ++g) total = h64::jadd(total, part[(size_t)w * ranges + g]);
   }
-  *out = acc;
+  stamp("horner");
+  return h64::store(total);
 }
 
 }  // namespace
 
 // sum_i k_i * P_i on `threads` host threads.  scalars: 32-byte LE (Montgomery if scalars_mont), points: 64-byte
-// affine Montgomery LE with (0,0) = identity.
+// affine Montgomery LE with (0,0) = identity.  The result is NOT normalised (callers add it to a GPU partial first).
 Jacobian host_msm(const u256* scalars, int scalars_mont, const Affine* points, size_t n, int threads) {
   if (n == 0) return jac_identity();
-  threads = std::max(1, std::min<int>(threads, (int)std::min<size_t>(n, 256)));
-  std::vector<Jacobian> res(threads);
-  std::vector<std::thread> pool;
-  for (int t = 0; t < threads; ++t) {
-    const size_t lo = n * t / threads, hi = n * (t + 1) / threads;
-    pool.emplace_back(msm_slice, scalars + lo, scalars_mont, points + lo, hi - lo, &res[t]);
-  }
-  Jacobian total = jac_identity();
-  for (int t = 0; t < threads; ++t) {
-    pool[t].join();
-    total = jac_add(total, res[t]);
-  }
-  return total;
+  return run(scalars, scalars_mont, (const Aff*)points, n, threads);
 }
 
 }  // namespace msm_amd
+
+extern "C" {
+
+// The CPU MSM as an entry point of its own: no ctx, no GPU (`gpu_profiler <log> <inst> cpu`).  h2c affine points;
+// scalars MONT_LE or CANON_LE.  threads <= 0: every CPU the process may run on.
+int msm_amd_host_msm(int scalar_layout, int point_layout, const void* scalars, const void* points, size_t n, int threads,
+                     void* out96) {
+  using namespace msm_amd;
+  if (!scalars || !points || !out96 || n == 0) return MSM_AMD_INPUT_ERROR;
+  if (point_layout != MSM_AMD_POINT_H2C_AFFINE) return MSM_AMD_INPUT_ERROR;
+  if (scalar_layout != MSM_AMD_SCALAR_MONT_LE && scalar_layout != MSM_AMD_SCALAR_CANON_LE) return MSM_AMD_INPUT_ERROR;
+  if (threads <= 0) threads = msm_amd_host_threads();
+  const Jacobian r = host_msm((const u256*)scalars, scalar_layout == MSM_AMD_SCALAR_MONT_LE, (const Affine*)points, n, threads);
+  const h64::Jac nrm = h64::normalise(h64::load(r));
+  std::memcpy(out96, &nrm, 96);
+  return MSM_AMD_OK;
+}
+
+// The deterministic synthetic instance of msm_amd_generate_instance, generated on the host (same generator code,
+// identical bytes): `gpu_profiler ... cpu` needs no GPU at all, like the reference's `cpu` mode.
+int msm_amd_generate_instance_host(uint64_t seed, size_t n, int scalars_mont, void* points, void* scalars, int threads) {
+  using namespace msm_amd;
+  if (!points || !scalars || n == 0) return MSM_AMD_INPUT_ERROR;
+  if (threads <= 0) threads = msm_amd_host_threads();
+  threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, (n + 255) / 256));
+  Affine* P = (Affine*)points;
+  u256* K = (u256*)scalars;
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    for (;;) {
+      const size_t lo = next.fetch_add(256, std::memory_order_relaxed);
+      if (lo >= n) break;
+      for (size_t t = lo; t < std::min(n, lo + 256); ++t) {
+        Affine pt;
+        pt.x = u256_zero();
+        pt.y = u256_zero();
+        for (uint32_t attempt = 0; attempt < 64; ++attempt)
+          if (gen_point_attempt(seed, t, attempt, pt)) break;
+        P[t] = pt;
+        u256 k = gen_scalar_canonical(seed, t);
+        if (scalars_mont) k = Fr::to_mont(k);
+        K[t] = k;
+      }
+    }
+  };
+  std::vector<std::thread> team;
+  for (int t = 1; t < threads; ++t) team.emplace_back(worker);
+  worker();
+  for (std::thread& th : team) th.join();
+  return MSM_AMD_OK;
+}
+
+// CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota when there is one (a GPU box
+// shows 256 logical CPUs and grants 16: one thread per VISIBLE CPU runs 16 threads' worth of quota on 256 threads).
+int msm_amd_host_threads(void) {
+  static const int cached = [] {
+    int cpus = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
+    long long quota = -1, period = 100000;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota|max> <period>"
+      char q[64] = {0};
+      if (std::fscanf(f, "%63s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atoll(q);
+      std::fclose(f);
+    } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+      if (std::fscanf(g, "%lld", &quota) != 1) quota = -1;
+      std::fclose(g);
+      if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (std::fscanf(h, "%lld", &period) != 1) period = 100000;
+        std::fclose(h);
+      }
+    }
+    if (quota > 0 && period > 0) cpus = std::min<int>(cpus, (int)std::max<long long>(1, (quota + period - 1) / period));
+    return std::max(1, cpus);
+  }();
+  return cached;
+}
+
+}  // extern "C"

@@ -65,6 +65,20 @@ build_tables_kernel(const Affine* __restrict__ in, uint32_t n, uint32_t c, uint3
   }
 }
 
+// Test aid for the bounded host waits (msm_amd_test_hold): ONE lane that keeps its stream busy until the host sets
+// *release or `max_ticks` of the 100 MHz wall clock have passed -- an exit condition the wave reaches whatever the
+// host does.
+__global__ void __launch_bounds__(64)
+hold_kernel(const volatile uint32_t* release, uint64_t max_ticks) {
+  if (threadIdx.x != 0) return;
+  const uint64_t t0 = wall_clock64();
+  while (*release == 0u && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(127);
+}
+
+void launch_hold(hipStream_t st, const uint32_t* release, uint64_t max_ticks) {
+  hipLaunchKernelGGL(hold_kernel, dim3(1), dim3(64), 0, st, (const volatile uint32_t*)release, max_ticks);
+}
+
 void launch_build_tables(hipStream_t st, const Affine* in, uint32_t n, uint32_t c, uint32_t W, AffPacked* tables) {
   hipLaunchKernelGGL(build_tables_kernel, dim3((n + 63) / 64), dim3(64), 0, st, in, n, c, W, tables);
 }

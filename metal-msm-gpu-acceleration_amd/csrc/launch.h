@@ -106,6 +106,7 @@ void launch_radix_sort_pairs(hipStream_t st, uint2* a, uint2* b, size_t n, uint3
 void launch_ref_accumulate(hipStream_t st, const uint2* pairs, size_t n_pairs, const Jacobian* points,
                            uint32_t n_points, uint32_t total_buckets, Jacobian* buckets);
 void launch_pad_buckets(hipStream_t st, const Jacobian* in, uint32_t bs, uint32_t W, uint32_t lb, PtI* out);
+void launch_hold(hipStream_t st, const uint32_t* release, uint64_t max_ticks);
 void launch_filter_count(hipStream_t st, const u256* scalars, uint32_t n, uint32_t* block_counts);
 void launch_filter_scatter(hipStream_t st, const u256* scalars, const Affine* points, uint32_t n,
                            const uint32_t* block_counts, u256* out_scalars, Affine* out_points);

@@ -1,0 +1,295 @@
+// Instance sharding over several contexts (GPUs) below the C ABI, and the RCCL gather of the 96-byte results.
+//
+// The loop being sharded is the reference's instance loop (src/bin/gpu_profiler.rs:101-106,
+// benches/msm_benchmark.rs:29-34): MSM instances are independent, so instance j goes to ctx j mod G, every ctx is
+// driven by its own host thread (pinned to the NUMA node of its GPU when sysfs tells), and no data-path collective
+// exists -- the only exchange is the gather of ceil(I / G) x 96 bytes per rank at the end.
+// In ONE process the results of all ctxs already land in the caller's buffer; the RCCL all-gather
+// (msm_amd_gather_*) is what a rank-per-GPU deployment uses, and what `gpu_profiler --gpus N` runs so that every
+// rank ends up with every result, over xGMI.
+//
+// RCCL is loaded with dlopen at msm_amd_gather_init, not linked: a process that already hosts an RCCL (PyTorch's
+// wheel ships its own) keeps using that one, and libmsm_amd.so has no hard dependency on it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <sched.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/msm_amd.h"
+
+namespace {
+
+// "0-7,64-71" -> cpu_set_t
+bool parse_cpulist(const char* s, cpu_set_t* set) {
+  CPU_ZERO(set);
+  bool any = false;
+  while (*s) {
+    char* end = nullptr;
+    const long a = std::strtol(s, &end, 10);
+    if (end == s) break;
+    long b = a;
+    s = end;
+    if (*s == '-') {
+      b = std::strtol(s + 1, &end, 10);
+      if (end == s + 1) break;
+      s = end;
+    }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) {
+      if (c >= 0) {
+        CPU_SET((int)c, set);
+        any = true;
+      }
+    }
+    while (*s == ',' || *s == ' ' || *s == '\n') ++s;
+  }
+  return any;
+}
+
+bool read_line(const std::string& path, char* buf, size_t len) {
+  FILE* f = std::fopen(path.c_str(), "r");
+  if (!f) return false;
+  const bool ok = std::fgets(buf, (int)len, f) != nullptr;
+  std::fclose(f);
+  return ok;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t msm_amd_shard_owner(size_t instance, size_t n_ctx) { return n_ctx ? instance % n_ctx : 0; }
+
+size_t msm_amd_shard_count(size_t n_inst, size_t n_ctx, size_t k) {
+  if (n_ctx == 0 || k >= n_ctx) return 0;
+  return n_inst / n_ctx + (k < n_inst % n_ctx ? 1 : 0);
+}
+
+// Restrict the calling thread to the CPUs local to `device` (its PCI function's local_cpulist in sysfs), intersected
+// with the CPUs the thread may use now.  0 = pinned; 1 = nothing to do (no NUMA information, or the intersection is
+// empty -- a container that was granted CPUs of another node); never an error for the MSM itself.
+int msm_amd_pin_thread_to_device(int device) {
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return 1;
+  }
+  for (char* c = bus; *c; ++c) *c = (char)std::tolower(*c);
+  const std::string dir = std::string("/sys/bus/pci/devices/") + bus;
+  char line[4096];
+  if (!read_line(dir + "/numa_node", line, sizeof line) || std::atoi(line) < 0) return 1;
+  if (!read_line(dir + "/local_cpulist", line, sizeof line)) return 1;
+  cpu_set_t local, now, both;
+  if (!parse_cpulist(line, &local)) return 1;
+  if (sched_getaffinity(0, sizeof now, &now) != 0) return 1;
+  CPU_AND(&both, &local, &now);
+  if (CPU_COUNT(&both) == 0) return 1;
+  return sched_setaffinity(0, sizeof both, &both) == 0 ? 0 : 1;
+}
+
+// msm_amd_msm_batch over several ctxs: instance j runs on ctxs[j mod n_ctx]; one host thread per ctx (the caller's
+// thread drives ctxs[0]); results land at out + 96 j.  With host buffers (device = 0) every ctx uploads its own
+// instances; with device = 1 the buffers of instance j must live on the device of ctxs[j mod n_ctx].
+static int batch_multi(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout, size_t n_inst,
+                       const void* const* scalars, const void* const* points, const size_t* n, void* out, int device) {
+  if (!ctxs || n_ctx == 0 || !scalars || !points || !n || !out || n_inst == 0) return MSM_AMD_INPUT_ERROR;
+  for (size_t k = 0; k < n_ctx; ++k) {
+    if (!ctxs[k]) return MSM_AMD_INPUT_ERROR;
+    for (size_t l = 0; l < k; ++l)
+      if (ctxs[l] == ctxs[k]) return MSM_AMD_INPUT_ERROR;   // one thread per ctx: a ctx listed twice would serialise
+  }
+  const size_t G = std::min(n_ctx, n_inst);
+  std::vector<int> rc(G, MSM_AMD_OK);
+  auto run = [&](size_t k, bool pin) {
+    cpu_set_t before;
+    const bool restore = pin && sched_getaffinity(0, sizeof before, &before) == 0;
+    if (pin) (void)msm_amd_pin_thread_to_device(msm_amd_ctx_device(ctxs[k]));
+    const size_t cnt = msm_amd_shard_count(n_inst, G, k);
+    std::vector<const void*> sp(cnt), pp(cnt);
+    std::vector<size_t> nn(cnt);
+    std::vector<uint8_t> res(cnt * 96);
+    for (size_t i = 0; i < cnt; ++i) {
+      const size_t j = k + i * G;
+      sp[i] = scalars[j];
+      pp[i] = points[j];
+      nn[i] = n[j];
+    }
+    rc[k] = device ? msm_amd_msm_batch_device(ctxs[k], scalar_layout, point_layout, cnt, sp.data(), pp.data(), nn.data(),
+                                              res.data())
+                   : msm_amd_msm_batch(ctxs[k], scalar_layout, point_layout, cnt, sp.data(), pp.data(), nn.data(),
+                                       res.data());
+    if (rc[k] == MSM_AMD_OK)
+      for (size_t i = 0; i < cnt; ++i) std::memcpy((uint8_t*)out + (k + i * G) * 96, res.data() + i * 96, 96);
+    if (restore) (void)sched_setaffinity(0, sizeof before, &before);   // the caller's thread gets its mask back
+  };
+  std::vector<std::thread> threads;
+  for (size_t k = 1; k < G; ++k) threads.emplace_back(run, k, true);
+  run(0, G > 1);
+  for (std::thread& t : threads) t.join();
+  for (size_t k = 0; k < G; ++k)
+    if (rc[k]) return rc[k];
+  return MSM_AMD_OK;
+}
+
+int msm_amd_msm_batch_multi(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout, size_t n_inst,
+                            const void* const* scalars, const void* const* points, const size_t* n, void* out) {
+  return batch_multi(ctxs, n_ctx, scalar_layout, point_layout, n_inst, scalars, points, n, out, 0);
+}
+
+int msm_amd_msm_batch_multi_device(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout,
+                                   size_t n_inst, const void* const* d_scalars, const void* const* d_points,
+                                   const size_t* n, void* out_host) {
+  return batch_multi(ctxs, n_ctx, scalar_layout, point_layout, n_inst, d_scalars, d_points, n, out_host, 1);
+}
+
+// ---- RCCL gather ---------------------------------------------------------------------------------------------------
+struct msm_amd_gather {
+  void* lib = nullptr;
+  int n = 0;
+  std::vector<int> devices;
+  std::vector<ncclComm_t> comms;
+  std::vector<hipStream_t> streams;
+  std::vector<void*> send, recv;
+  size_t cap = 0;   // bytes per rank the device buffers hold
+  std::string error;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+const char* msm_amd_gather_last_error(const msm_amd_gather* g) { return g ? g->error.c_str() : ""; }
+
+void msm_amd_gather_destroy(msm_amd_gather* g) {
+  if (!g) return;
+  for (int k = 0; k < (int)g->streams.size(); ++k) {
+    (void)hipSetDevice(g->devices[k]);
+    if (g->streams[k]) (void)hipStreamSynchronize(g->streams[k]);
+  }
+  for (int k = 0; k < (int)g->comms.size(); ++k)
+    if (g->comms[k] && g->CommDestroy) (void)g->CommDestroy(g->comms[k]);
+  for (int k = 0; k < (int)g->streams.size(); ++k) {
+    (void)hipSetDevice(g->devices[k]);
+    if (k < (int)g->send.size() && g->send[k]) (void)hipFree(g->send[k]);
+    if (k < (int)g->recv.size() && g->recv[k]) (void)hipFree(g->recv[k]);
+    if (g->streams[k]) (void)hipStreamDestroy(g->streams[k]);
+  }
+  (void)hipGetLastError();
+  // the library stays loaded: unloading an RCCL whose proxy threads are winding down is not worth the risk
+  delete g;
+}
+
+// One communicator per listed device, all in this process (ncclCommInitAll).  RCCL refuses a device listed twice.
+int msm_amd_gather_init(const int* devices, int n_devices, msm_amd_gather** out) {
+  if (!devices || n_devices <= 0 || !out) return MSM_AMD_INPUT_ERROR;
+  *out = nullptr;
+  msm_amd_gather* g = new msm_amd_gather();
+  g->n = n_devices;
+  g->devices.assign(devices, devices + n_devices);
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  g->lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);   // the RCCL this process already hosts, if any
+  for (const char* nm : names) {
+    if (g->lib) break;
+    g->lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+  }
+  if (!g->lib) {
+    std::fprintf(stderr, "msm_amd_gather_init: cannot load librccl: %s\n", dlerror());
+    delete g;
+    return MSM_AMD_LIBRARY_ERROR;
+  }
+  g->CommInitAll = (decltype(g->CommInitAll))dlsym(g->lib, "ncclCommInitAll");
+  g->CommDestroy = (decltype(g->CommDestroy))dlsym(g->lib, "ncclCommDestroy");
+  g->AllGather = (decltype(g->AllGather))dlsym(g->lib, "ncclAllGather");
+  g->GroupStart = (decltype(g->GroupStart))dlsym(g->lib, "ncclGroupStart");
+  g->GroupEnd = (decltype(g->GroupEnd))dlsym(g->lib, "ncclGroupEnd");
+  g->GetErrorString = (decltype(g->GetErrorString))dlsym(g->lib, "ncclGetErrorString");
+  if (!g->CommInitAll || !g->CommDestroy || !g->AllGather || !g->GroupStart || !g->GroupEnd || !g->GetErrorString) {
+    std::fprintf(stderr, "msm_amd_gather_init: librccl lacks a collective entry point\n");
+    delete g;
+    return MSM_AMD_FUNCTION_ERROR;
+  }
+  g->comms.assign(n_devices, nullptr);
+  const ncclResult_t r = g->CommInitAll(g->comms.data(), n_devices, devices);
+  if (r != ncclSuccess) {
+    std::fprintf(stderr, "msm_amd_gather_init: ncclCommInitAll: %s\n", g->GetErrorString(r));
+    g->comms.clear();
+    msm_amd_gather_destroy(g);
+    return MSM_AMD_PIPELINE_ERROR;
+  }
+  g->streams.assign(n_devices, nullptr);
+  g->send.assign(n_devices, nullptr);
+  g->recv.assign(n_devices, nullptr);
+  for (int k = 0; k < n_devices; ++k) {
+    if (hipSetDevice(devices[k]) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->streams[k], hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      msm_amd_gather_destroy(g);
+      return MSM_AMD_PIPELINE_ERROR;
+    }
+  }
+  *out = g;
+  return MSM_AMD_OK;
+}
+
+int msm_amd_gather_size(const msm_amd_gather* g) { return g ? g->n : 0; }
+
+// All-gather of bytes_per_rank bytes from every rank: send_host[k] is rank k's contribution, recv_host[k] (n x
+// bytes_per_rank) receives everybody's, in rank order, through device buffers on rank k's GPU.
+int msm_amd_gather_all(msm_amd_gather* g, const void* const* send_host, size_t bytes_per_rank, void* const* recv_host) {
+  if (!g || !send_host || !recv_host || bytes_per_rank == 0) return MSM_AMD_INPUT_ERROR;
+  auto hip_fail = [&](hipError_t e, const char* what) {
+    (void)hipGetLastError();
+    g->error = std::string(what) + ": " + hipGetErrorString(e);
+    return (int)MSM_AMD_PIPELINE_ERROR;
+  };
+  hipError_t e;
+  if (bytes_per_rank > g->cap) {
+    for (int k = 0; k < g->n; ++k) {
+      if ((e = hipSetDevice(g->devices[k])) != hipSuccess) return hip_fail(e, "hipSetDevice");
+      if (g->send[k]) (void)hipFree(g->send[k]);
+      if (g->recv[k]) (void)hipFree(g->recv[k]);
+      g->send[k] = g->recv[k] = nullptr;
+      if ((e = hipMalloc(&g->send[k], bytes_per_rank)) != hipSuccess) return hip_fail(e, "hipMalloc");
+      if ((e = hipMalloc(&g->recv[k], bytes_per_rank * (size_t)g->n)) != hipSuccess) return hip_fail(e, "hipMalloc");
+    }
+    g->cap = bytes_per_rank;
+  }
+  for (int k = 0; k < g->n; ++k) {
+    if (!send_host[k] || !recv_host[k]) return MSM_AMD_INPUT_ERROR;
+    if ((e = hipSetDevice(g->devices[k])) != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if ((e = hipMemcpyAsync(g->send[k], send_host[k], bytes_per_rank, hipMemcpyHostToDevice, g->streams[k])) != hipSuccess)
+      return hip_fail(e, "hipMemcpyAsync");
+  }
+  ncclResult_t r = g->GroupStart();
+  for (int k = 0; r == ncclSuccess && k < g->n; ++k)
+    r = g->AllGather(g->send[k], g->recv[k], bytes_per_rank, ncclUint8, g->comms[k], g->streams[k]);
+  const ncclResult_t r2 = g->GroupEnd();
+  if (r == ncclSuccess) r = r2;
+  if (r != ncclSuccess) {
+    g->error = std::string("ncclAllGather: ") + g->GetErrorString(r);
+    return MSM_AMD_PIPELINE_ERROR;
+  }
+  for (int k = 0; k < g->n; ++k) {
+    if ((e = hipSetDevice(g->devices[k])) != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if ((e = hipMemcpyAsync(recv_host[k], g->recv[k], bytes_per_rank * (size_t)g->n, hipMemcpyDeviceToHost,
+                            g->streams[k])) != hipSuccess)
+      return hip_fail(e, "hipMemcpyAsync");
+  }
+  for (int k = 0; k < g->n; ++k) {
+    if ((e = hipSetDevice(g->devices[k])) != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if ((e = hipStreamSynchronize(g->streams[k])) != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+  }
+  return MSM_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+"""Several contexts below the C ABI: msm_amd_msm_batch_multi shards the reference's instance
+loop (gpu_profiler.rs:101-106) as instance j -> ctx j mod G with one host thread per ctx.  One GPU is available to
+the tests, so the contexts share it: that still proves the library has no hidden globals between contexts and that
+two of them run concurrently from two threads.  The RCCL gather runs with the ranks this box has (one)."""
+import json
+import os
+import subprocess
+import threading
+
+import pytest
+
+from oracle import bn254_ref as o
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "metal-msm-gpu-acceleration_amd", "gpu_profiler")
+
+
+def _same(a, b):
+    return o.decode_jacobian_mont_le(a) == o.decode_jacobian_mont_le(b)
+
+
+def test_two_contexts_on_one_device_through_batch_multi(cfg, msm_pkg):
+    sizes = [1 << 12, 3000, 1 << 14, 17, 1 << 13]          # 5 instances over 2 contexts: 3 + 2
+    inst = [co.gen_instance(o.SEED_BASE + 40 + j, n) for j, n in enumerate(sizes)]
+    want = [co.msm_best(sc, pts, n) for (pts, sc), n in zip(inst, sizes)]
+    second = msm_pkg.setup_metal_state(cfg.device())
+    try:
+        got = msm_pkg.msm_batch_multi([cfg, second], [sc for _p, sc in inst], [p for p, _s in inst], sizes)
+        assert all(_same(g, w) for g, w in zip(got, want))
+        assert got == cfg.msm_batch([sc for _p, sc in inst], [p for p, _s in inst], sizes)   # same bytes as one ctx
+        # device-resident variant: instance j's buffers allocated through ITS ctx
+        ctxs = [cfg, second]
+        dps, dss = [], []
+        for j, ((pts, sc), n) in enumerate(zip(inst, sizes)):
+            c = ctxs[msm_pkg.shard_owner(j, 2)]
+            dp, ds = c.alloc(64 * n), c.alloc(32 * n)
+            c.to_device(dp, pts)
+            c.to_device(ds, sc)
+            dps.append(dp)
+            dss.append(ds)
+        try:
+            got_dev = msm_pkg.msm_batch_multi(ctxs, dss, dps, sizes, device=True)
+            assert got_dev == got
+        finally:
+            for j, (dp, ds) in enumerate(zip(dps, dss)):
+                ctxs[msm_pkg.shard_owner(j, 2)].free(dp)
+                ctxs[msm_pkg.shard_owner(j, 2)].free(ds)
+        # more contexts than instances, and a ctx listed twice
+        assert msm_pkg.msm_batch_multi([cfg, second], [inst[0][1]], [inst[0][0]], [sizes[0]]) == [got[0]]
+        with pytest.raises(msm_pkg.MsmError):
+            msm_pkg.msm_batch_multi([cfg, cfg], [sc for _p, sc in inst], [p for p, _s in inst], sizes)
+    finally:
+        second.close()
+
+
+def test_two_contexts_driven_from_two_python_threads(cfg, msm_pkg):
+    """The header's promise: calls on one ctx are serialised, different ctxs run concurrently."""
+    n = 1 << 15
+    inst = [co.gen_instance(o.SEED_BASE + 60 + j, n) for j in range(2)]
+    want = [co.msm_best(sc, pts, n) for pts, sc in inst]
+    second = msm_pkg.setup_metal_state(cfg.device())
+    results = [[None] * 6, [None] * 6]
+    errors = []
+
+    def drive(k, c):
+        try:
+            pts, sc = inst[k]
+            for r in range(6):
+                results[k][r] = c.msm(sc, pts, n)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    try:
+        ts = [threading.Thread(target=drive, args=(k, c)) for k, c in enumerate((cfg, second))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+        for k in range(2):
+            assert all(_same(r, want[k]) for r in results[k])
+    finally:
+        second.close()
+
+
+def test_rccl_gather_from_cxx_with_the_ranks_this_box_has(cfg, msm_pkg):
+    """ncclCommInitAll + ncclAllGather through msm_amd_gather_*: one rank here (world size 1 still goes through
+    RCCL); the N-rank run is the driver's, on an 8-GPU node."""
+    g = msm_pkg.RcclGather([cfg.device()])
+    try:
+        block = bytes(range(96)) * 5                      # 5 results of one rank (config 3: 5 instances per GPU)
+        assert g.all_gather([block]) == [block]
+        bigger = bytes(reversed(range(96))) * 7           # the device buffers grow
+        assert g.all_gather([bigger]) == [bigger]
+    finally:
+        g.close()
+    with pytest.raises(msm_pkg.MsmError):                 # RCCL wants one rank per GPU
+        msm_pkg.RcclGather([cfg.device(), cfg.device()])
+
+
+def _run(*args):
+    r = subprocess.run([EXE, *args, "--json"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+
+
+def test_gpu_profiler_gpus_flag_matches_single_context():
+    """`gpu_profiler 16 6 gpu_resident 2 --gpus 1` (sharded path, RCCL gather of one rank) and two contexts on one
+    device give the results of the plain single-context run."""
+    single, _ = _run("16", "6", "gpu_resident", "2")
+    sharded, err = _run("16", "6", "gpu_resident", "2", "--devices", "0")
+    assert sharded["results_fnv1a64"] == single["results_fnv1a64"]
+    assert sharded["rccl_gather"] is True and "every rank holds all 6 results: yes" in err
+    shared, err2 = _run("16", "6", "gpu_resident", "2", "--devices", "0,0")
+    assert shared["results_fnv1a64"] == single["results_fnv1a64"] and shared["gpus"] == 2
+    assert "RCCL gather skipped" in err2
+    host, _ = _run("14", "5", "gpu", "1", "--devices", "0,0,0")
+    host1, _ = _run("14", "5", "gpu", "1")
+    assert host["results_fnv1a64"] == host1["results_fnv1a64"]
