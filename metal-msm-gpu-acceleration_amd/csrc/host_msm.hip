@@ -5,16 +5,18 @@
 //
 // Algorithm (written for this library, on the 4 x 64-bit host arithmetic of host_fq64.h):
 //   phase 0  scalars -> canonical -> signed c-bit digits, [window][point] int16, threads over point ranges
-//   phase 1  tasks (window, bucket range) with disjoint bucket sets: every task scans the window's digits and takes
-//            the points of its range; affine buckets are filled by BATCHED-AFFINE additions -- up to 512 pending
+//   phase 1  tasks (window, point group): affine buckets filled by BATCHED-AFFINE additions -- up to 512 pending
 //            (bucket, point) pairs with distinct buckets share one field inversion (Montgomery's trick, four
 //            interleaved product chains), ~8 field multiplications per addition instead of 11 for a Jacobian mixed
 //            addition; a point whose bucket is already pending in the batch goes to that bucket's Jacobian side
 //            accumulator instead (uniform scalars: a few per cent; all-equal scalars: all of them, still 11
-//            multiplications each -- no pathological case); the task then reduces its own buckets while they are in
-//            the cache: sum_b (b + 1) B_b = sum_range [ sum_{b in range} (b - lo + 1) B_b + lo * sum_{b in range} B_b ]
-//   phase 2  Horner over the windows (one thread; 254 doublings)
-// Tasks are handed out by an atomic counter; the team of threads lives for one call and meets at one spin barrier.
+//            multiplications each -- no pathological case).  (Tasks over bucket RANGES instead of point groups --
+//            disjoint bucket sets, nothing to merge -- were measured too: 18-24 ms against 15.7-17.5 ms at 2^16
+//            points on 16 threads, the strided reads of the points cost more than the merge.)
+//   phase 2  tasks (window, bucket segment): running sums over the segment across all groups, two interleaved chains,
+//            sum_b (b + 1) B_b = sum_seg [ sum_{b in seg} (b - lo + 1) B_b  +  lo * sum_{b in seg} B_b ]
+//   phase 3  Horner over the windows (one thread; 254 doublings)
+// Tasks are handed out by an atomic counter; the team of threads lives for one call and meets at spin barriers.
 // The window c minimises a cost model in field multiplications (window_for).
 #include <sched.h>
 
@@ -197,14 +199,12 @@ void flush(BucketSet& B, Pending& q) {
   q.count = 0;
 }
 
-// One task: window w, buckets [b_lo, b_hi).  Scans all n digits of the window (2 bytes per point) and takes the
-// points whose bucket falls into its range, so tasks own DISJOINT bucket sets: nothing to merge afterwards.
+// One phase-1 task: the points [lo, hi) of one window into B (all 2^(c-1) buckets of the window).
 // `batch` = pending additions per shared inversion; 0 = no batched-affine additions at all (every point goes to its
 // bucket's Jacobian accumulator): windows with few buckets or tasks with few points cannot fill a batch, and an
 // inversion costs ~380 multiplications.
-void fill_buckets(BucketSet& B, Pending& q, const int16_t* digits, const Aff* points, size_t p_lo, size_t p_hi,
-                  uint32_t b_lo, uint32_t b_hi, int batch) {
-  const uint32_t nbuckets = b_hi - b_lo;
+void fill_buckets(BucketSet& B, Pending& q, const int16_t* digits, const Aff* points, size_t lo, size_t hi,
+                  uint32_t nbuckets, int batch) {
   B.aff.resize(nbuckets);
   B.full.assign(nbuckets, 0);
   B.stamp.assign(nbuckets, batch ? 0u : 1u);   // batch == 0: every bucket looks "pending" -> Jacobian path
@@ -212,14 +212,12 @@ void fill_buckets(BucketSet& B, Pending& q, const int16_t* digits, const Aff* po
   B.any_side = false;
   uint32_t batch_id = 1;
   q.count = 0;
-  for (size_t i = p_lo; i < p_hi; ++i) {
+  for (size_t i = lo; i < hi; ++i) {
     const int32_t d = digits[i];
     if (d == 0) continue;
-    const uint32_t slot = (uint32_t)(d < 0 ? -d : d) - 1;
-    if (slot < b_lo || slot >= b_hi) continue;
     const Aff& src = points[i];
     if (h64::is_zero(src.x) && h64::is_zero(src.y)) continue;   // affine identity (0, 0)
-    const uint32_t b = slot - b_lo;
+    const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
     Aff p = src;
     if (d < 0) p.y = fe_neg(p.y);
     if (B.stamp[b] == batch_id) {   // its bucket already has an addition pending in this batch
@@ -247,61 +245,79 @@ void fill_buckets(BucketSet& B, Pending& q, const int16_t* digits, const Aff* po
   flush(B, q);
 }
 
-// sum_{b in [0, nb)} (b + 1) B_b of one task's buckets by running sums, as TWO interleaved chains (upper and lower
-// half of the range): a running sum is a string of dependent field multiplications, two independent ones in one loop
-// let the out-of-order core overlap them.  With m = nb / 2:
-//   sum = [ sum_{b >= m} (b - m + 1) B_b + m * sum_{b >= m} B_b ]  +  sum_{b < m} (b + 1) B_b
-// Also returns sum_b B_b (the caller adds b_lo times it for a task that does not start at bucket 0).
-void reduce_buckets(const BucketSet& B, uint32_t nb, Jac* weighted, Jac* plain) {
+// One phase-2 task: sum_{b in [lo, hi)} (b + 1) B_b where B_b is the sum over the window's point groups, by running
+// sums -- as TWO interleaved chains (upper and lower half of the segment): a running sum is a string of dependent
+// field multiplications (bound by the multiplier's latency), two independent ones in one loop overlap in the
+// out-of-order core.  With m = lo + (hi - lo) / 2:
+//   sum = [ sum_{b >= m} (b - m + 1) B_b + m * sum_{b >= m} B_b ]  +  [ sum_{b < m} (b - lo + 1) B_b + lo * sum_{b < m} B_b ]
+Jac reduce_segment(const BucketSet* groups, uint32_t n_groups, uint32_t lo, uint32_t hi) {
   auto step = [&](uint32_t b, Jac& running, Jac& acc) {
-    if (B.full[b]) running = jmadd(running, B.aff[b]);
-    if (B.any_side && !h64::is_identity(B.side[b])) running = h64::jadd(running, B.side[b]);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+      const BucketSet& S = groups[g];
+      if (S.full[b]) running = jmadd(running, S.aff[b]);
+      if (S.any_side && !h64::is_identity(S.side[b])) running = h64::jadd(running, S.side[b]);
+    }
     acc = h64::jadd(acc, running);
   };
-  const uint32_t m = nb / 2;
+  const uint32_t m = lo + (hi - lo) / 2;
   Jac run_hi = h64::identity(), acc_hi = h64::identity(), run_lo = h64::identity(), acc_lo = h64::identity();
-  for (uint32_t k = 0; k < m; ++k) {   // both halves top-down; the upper half has nb - m >= m buckets
-    step(nb - 1 - k, run_hi, acc_hi);
-    step(m - 1 - k, run_lo, acc_lo);
+  uint32_t bh = hi, bl = m;
+  while (bl > lo) {   // the upper half [m, hi) has as many buckets as the lower [lo, m), or one more
+    step(--bh, run_hi, acc_hi);
+    step(--bl, run_lo, acc_lo);
   }
-  if ((nb - m) > m) step(m, run_hi, acc_hi);   // odd nb: the upper half's last bucket
+  while (bh > m) step(--bh, run_hi, acc_hi);
   Jac total = h64::jadd(acc_hi, acc_lo);
   if (m) total = h64::jadd(total, jmul_small(run_hi, m));
-  *weighted = total;
-  *plain = h64::jadd(run_hi, run_lo);
+  if (lo) total = h64::jadd(total, jmul_small(run_lo, lo));
+  return total;
 }
 
-// Cost model in field multiplications.  One addition into a bucket: Jacobian mixed addition 11; batched-affine 6 + its
-// share of the inversion (~384 / batch) + the collisions that fall back to the Jacobian accumulator (about
-// batch / (2 buckets) of the points, 11 each), with batch = a quarter of the task's buckets, at most kBatch.
-// Reduction per window and bucket: one mixed addition (11) and one full addition (16).
+// Cost model in field multiplications, as the MAKESPAN of the two task phases on `threads` threads (tasks are equal
+// in size, so a phase takes ceil(tasks / threads) task times: 40 tasks on 16 threads cost as much as 48).
+//   one addition into a bucket: Jacobian mixed addition 11; batched-affine 6 + its share of the inversion
+//   (~384 / batch) + the collisions that fall back to the Jacobian accumulator (about batch / (2 buckets) of the
+//   points, 11 each), with batch = a quarter of the buckets, at most kBatch;
+//   phase 2 per window and bucket: `groups` mixed additions (11) and one full addition (16), weighted 1.3 because the
+//   running sums are bound by latency rather than throughput.
+// Measured on an EPYC 9575F, 16 threads, 2^16 points (`gpu_profiler 16 1 cpu 5`, profiles/r03_cpu_msm_sweep.txt):
+// c = 11 with 2 groups (48 tasks) 13.4 ms, c = 12 / 2 groups (44 tasks) 13.9, c = 13 / 4 groups (80 tasks) 14.3,
+// c = 13 / 2 groups (40 tasks) 15.6 -- the order this model gives.
 struct Choice {
   uint32_t c;
-  uint32_t ranges;   // bucket ranges (= tasks) per window
+  uint32_t groups;   // point groups per window (phase-1 tasks = windows x groups)
   int batch;         // 0 = Jacobian accumulators only
 };
-int batch_for(uint32_t buckets_per_task, size_t points_per_task) {
-  const int batch = (int)std::min<size_t>(kBatch, buckets_per_task / 4);
+int batch_for(uint32_t c, size_t points_per_task) {
+  const int batch = (int)std::min<size_t>(kBatch, ((size_t)1 << (c - 1)) / 4);
   if (batch < 8 || points_per_task < (size_t)4 * batch) return 0;
-  const double cost = 6.0 + 384.0 / batch + 11.0 * batch / (2.0 * buckets_per_task);
+  const double nb = (double)(1u << (c - 1));
+  const double cost = 6.0 + 384.0 / batch + 11.0 * batch / (2.0 * nb);
   return cost < 11.0 ? batch : 0;
+}
+uint32_t segments_for(uint32_t c, uint32_t groups, int threads) {   // phase-2 tasks per window, >= 32 buckets each
+  const uint32_t half = 1u << (c - 1);
+  return threads <= 1 ? 1u : std::max(1u, std::min(groups, half / 32 ? half / 32 : 1u));
 }
 Choice window_for(size_t n, int threads) {
   if (n < 32) return {3, 1, 0};   // the reference's policy for tiny instances (msm.rs:137-138)
   Choice best{4, 1, 0};
   double best_cost = 1e300;
+  const uint32_t max_groups = threads <= 1 ? 1u : 8u;
   for (uint32_t c = 4; c <= 15; ++c) {
-    const uint32_t W = 254 / c + 1, nb = 1u << (c - 1);
-    // about three tasks per thread, each with at least 32 buckets
-    uint32_t ranges = threads > 1 ? (uint32_t)((3 * threads + W - 1) / W) : 1u;
-    ranges = std::max(1u, std::min(ranges, nb / 32 ? nb / 32 : 1u));
-    const int batch = batch_for(nb / ranges, n / ranges);
-    const double add = batch ? 6.0 + 384.0 / batch + 11.0 * batch / (2.0 * (nb / ranges)) : 11.0;
-    // every task scans the window's n digits: ~0.05 multiplications' worth each
-    const double cost = (double)W * ((double)n * add + (double)nb * 27.0 + 0.05 * (double)n * ranges);
-    if (cost < best_cost) {
-      best_cost = cost;
-      best = {c, ranges, batch};
+    const uint32_t W = 254 / c + 1;
+    const double nb = (double)(1u << (c - 1));
+    for (uint32_t groups = 1; groups <= max_groups; ++groups) {
+      if (groups > 1 && n / groups < 256) break;
+      const int batch = batch_for(c, n / groups);
+      const double add = batch ? 6.0 + 384.0 / batch + 11.0 * batch / (2.0 * nb) : 11.0;
+      const uint32_t segs = segments_for(c, groups, threads);
+      const double rounds1 = std::ceil((double)W * groups / threads), rounds2 = std::ceil((double)W * segs / threads);
+      const double cost = rounds1 * ((double)n / groups) * add + rounds2 * (nb / segs) * 1.3 * (11.0 * groups + 16.0);
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = {c, groups, batch};
+      }
     }
   }
   return best;
@@ -310,34 +326,34 @@ Choice window_for(size_t n, int threads) {
 Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n, int threads) {
   const int T = std::max(1, std::min<int>(threads, (int)std::min<size_t>((n + 63) / 64, 256)));
   Choice choice = window_for(n, T);
-  if (const char* e = std::getenv("MSM_AMD_HOST_WINDOW")) {   // experiments
+  if (const char* e = std::getenv("MSM_AMD_HOST_WINDOW")) {   // experiments (tools/dbg/cpu_sweep.sh)
     const int v = std::atoi(e);
     if (v >= 3 && v <= 15) choice.c = (uint32_t)v;
   }
-  if (const char* e = std::getenv("MSM_AMD_HOST_RANGES")) {
+  if (const char* e = std::getenv("MSM_AMD_HOST_GROUPS")) {
     const int v = std::atoi(e);
-    if (v >= 1 && (uint32_t)v <= (1u << (choice.c - 1))) choice.ranges = (uint32_t)v;
+    if (v >= 1 && v <= 64) choice.groups = (uint32_t)v;
   }
-  if (std::getenv("MSM_AMD_HOST_WINDOW") || std::getenv("MSM_AMD_HOST_RANGES"))
-    choice.batch = batch_for((1u << (choice.c - 1)) / choice.ranges, n / choice.ranges);
-  const uint32_t c = choice.c, ranges = choice.ranges;
+  if (std::getenv("MSM_AMD_HOST_WINDOW") || std::getenv("MSM_AMD_HOST_GROUPS"))
+    choice.batch = batch_for(choice.c, n / choice.groups);
+  const uint32_t c = choice.c, groups = choice.groups;
   const uint32_t W = 254 / c + 1;
   const uint32_t half = 1u << (c - 1);   // buckets per window: slot b <-> digit magnitude b + 1
-  const uint32_t range_len = (half + ranges - 1) / ranges;
+  const uint32_t segs = segments_for(c, groups, T);   // phase-2 tasks per window
+  const uint32_t seg_len = (half + segs - 1) / segs;
   std::vector<int16_t> digits((size_t)W * n);
-  std::vector<Jac> part((size_t)W * ranges);
+  std::vector<BucketSet> sets((size_t)W * groups);
+  std::vector<Jac> part((size_t)W * segs);
   std::atomic<size_t> next0{0}, next1{0}, next2{0};
-  const bool by_points = std::getenv("MSM_AMD_HOST_BY_POINTS") != nullptr;
-  std::vector<BucketSet> sets(by_points ? (size_t)W * ranges : 0);
   Barrier barrier(T);
   const size_t chunk0 = 1024;
   const bool trace = std::getenv("MSM_AMD_HOST_TRACE") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   auto stamp = [&](const char* what) {
     if (trace)
-      std::fprintf(stderr, "host_msm: %-8s %8.3f ms (n=%zu c=%u W=%u ranges=%u batch=%d T=%d)\n", what,
+      std::fprintf(stderr, "host_msm: %-8s %8.3f ms (n=%zu c=%u W=%u groups=%u segs=%u batch=%d T=%d)\n", what,
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), n, c, W,
-                   ranges, choice.batch, T);
+                   groups, segs, choice.batch, T);
   };
   auto worker = [&](int tid) {
     // ---- phase 0: digits
@@ -369,65 +385,39 @@ Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n,
     }
     barrier.wait();
     if (tid == 0) stamp("digits");
-    Pending* q = new Pending();
-    if (by_points) {   // EXPERIMENT: tasks (window, point group) with full bucket sets, merged in a second phase
+    // ---- phase 1: tasks (window, point group)
+    {
+      Pending* q = new Pending();
       for (;;) {
         const size_t t = next1.fetch_add(1, std::memory_order_relaxed);
-        if (t >= (size_t)W * ranges) break;
-        const uint32_t w = (uint32_t)(t / ranges), g = (uint32_t)(t % ranges);
-        fill_buckets(sets[t], *q, &digits[(size_t)w * n], points, n * g / ranges, n * (g + 1) / ranges, 0, half, choice.batch);
-      }
-      barrier.wait();
-      for (;;) {
-        const size_t t = next2.fetch_add(1, std::memory_order_relaxed);
-        if (t >= (size_t)W * ranges) break;
-        const uint32_t w = (uint32_t)(t / ranges), sgm = (uint32_t)(t % ranges);
-        const uint32_t lo = std::min(half, sgm * range_len), hi = std::min(half, lo + range_len);
-        Jac running = h64::identity(), acc = h64::identity();
-        for (uint32_t b = hi; b-- > lo;) {
-          for (uint32_t g = 0; g < ranges; ++g) {
-            const BucketSet& S = sets[(size_t)w * ranges + g];
-            if (S.full[b]) running = jmadd(running, S.aff[b]);
-            if (S.any_side && !h64::is_identity(S.side[b])) running = h64::jadd(running, S.side[b]);
-          }
-          acc = h64::jadd(acc, running);
-        }
-        if (lo) acc = h64::jadd(acc, jmul_small(running, lo));
-        part[t] = acc;
+        if (t >= (size_t)W * groups) break;
+        const uint32_t w = (uint32_t)(t / groups), g = (uint32_t)(t % groups);
+        fill_buckets(sets[t], *q, &digits[(size_t)w * n], points, n * g / groups, n * (g + 1) / groups, half,
+                     choice.batch);
       }
       delete q;
-      return;
     }
-    // ---- phase 1: tasks (window, bucket range): fill the buckets, reduce them while they are hot in the cache
-    BucketSet* B = new BucketSet();
+    barrier.wait();
+    if (tid == 0) stamp("buckets");
+    // ---- phase 2: tasks (window, bucket segment)
     for (;;) {
-      const size_t t = next1.fetch_add(1, std::memory_order_relaxed);
-      if (t >= (size_t)W * ranges) break;
-      const uint32_t w = (uint32_t)(t / ranges), g = (uint32_t)(t % ranges);
-      const uint32_t b_lo = std::min(half, g * range_len), b_hi = std::min(half, b_lo + range_len);
-      if (b_lo == b_hi) {
-        part[t] = h64::identity();
-        continue;
-      }
-      fill_buckets(*B, *q, &digits[(size_t)w * n], points, 0, n, b_lo, b_hi, choice.batch);
-      Jac weighted, plain;
-      reduce_buckets(*B, b_hi - b_lo, &weighted, &plain);
-      if (b_lo) weighted = h64::jadd(weighted, jmul_small(plain, b_lo));
-      part[t] = weighted;
+      const size_t t = next2.fetch_add(1, std::memory_order_relaxed);
+      if (t >= (size_t)W * segs) break;
+      const uint32_t w = (uint32_t)(t / segs), s = (uint32_t)(t % segs);
+      const uint32_t lo = std::min(half, s * seg_len), hi = std::min(half, lo + seg_len);
+      part[t] = lo < hi ? reduce_segment(&sets[(size_t)w * groups], groups, lo, hi) : h64::identity();
     }
-    delete B;
-    delete q;
   };
   std::vector<std::thread> team;
   for (int t = 1; t < T; ++t) team.emplace_back(worker, t);
   worker(0);
   for (std::thread& th : team) th.join();
-  stamp("buckets");
-  // ---- Horner over the windows (final_accumulation.rs:19-39)
+  stamp("segments");
+  // ---- phase 3: Horner over the windows (final_accumulation.rs:19-39)
   Jac total = h64::identity();
   for (int w = (int)W - 1; w >= 0; --w) {
     for (uint32_t i = 0; i < c; ++i) total = h64::jdouble(total);
-    for (uint32_t g = 0; g < ranges; ++g) total = h64::jadd(total, part[(size_t)w * ranges + g]);
+    for (uint32_t s = 0; s < segs; ++s) total = h64::jadd(total, part[(size_t)w * segs + s]);
   }
   stamp("horner");
   return h64::store(total);
