@@ -238,17 +238,32 @@ def main(argv=None):
                 "whole_pipeline_GBps": round(L.msm_amd_algorithmic_bytes(n, ref_window, 0) /
                                              (sum(tot_ms) / len(tot_ms) * 1e-3) / 1e9, 2)}
 
-    # ---- secondary roof (SURVEY 8d asks for it): the kernel is bound by quarter-rate 32-bit multiplies, not by HBM.
-    # Instruction counts from csrc/bn254_fq29.hip.h: a 9-limb Montgomery product is 81 + 81 v_mad_u64_u32 + 9
-    # v_mul_lo_u32 = 171 multiplier-pipe instructions, a squaring 135, two products with one reduction 252; a mixed
-    # addition (7 mul + 2 sqr + 1 double product) 1719, the affine+affine start of a work item 1035.  Peak: 1.81 wave
-    # instructions/ns/CU measured for v_mad_u64_u32 (profiles/r01_valu_rates_microbench.txt) x 256 CUs x 64 lanes.
+    # ---- secondary roof (SURVEY 8d asks for it): the kernel is bound by VALU issue, most of it multiplier instructions
+    # (v_mad_u64_u32 / v_mul_lo_u32), not by HBM.  The instruction counts per mixed addition (pti_madd, 8M + 2S on
+    # 9 x 29-bit limbs) and per affine + affine start of a work item (pti_mmadd, 4M + 2S, incl. the first product of
+    # pti_madd that the compiler speculates above the path split) are NOT typed in here: the build disassembles the
+    # shipped k_accumulate object and counts them (tools/isa_counts.py -> metal-msm-gpu-acceleration_amd/
+    # isa_counts.json).  Peak: 1.81 wave instructions/ns/CU measured for back-to-back v_mad_u64_u32 at 2 waves/SIMD
+    # (profiles/r01_valu_rates_microbench.txt: one every 5.3 cycles per SIMD, against 3.0 for v_add_u32)
+    # x 256 CUs x 64 lanes = 29.65 T lane-instructions/s.
+    isa_path = os.path.join(ROOT, "metal-msm-gpu-acceleration_amd", "isa_counts.json")
+    try:
+        isa = json.load(open(isa_path))
+        per_madd, per_start = float(isa["multiplier_per_mixed_addition"]), float(isa["multiplier_per_affine_start"])
+        valu_per_madd = isa.get("valu_per_mixed_addition")
+    except Exception as e:   # noqa: BLE001
+        raise SystemExit(f"bench.py: {isa_path} missing or unreadable ({e}): run __graft_entry__.build()")
     items = float(tm.reserved2[0])
-    lane_madds = n * tm.num_windows - 2.0 * items          # first point of an item is free, second is the 1035 one
-    mul_instr = lane_madds * 1719.0 + items * 1035.0
+    lane_madds = n * tm.num_windows - 2.0 * items          # first point of an item is free, second is the affine start
+    mul_instr = lane_madds * per_madd + items * per_start
     valu = {"bound": "valu-int32-multiply", "achieved": round(mul_instr / (acc_avg_ms * 1e-3) / 1e12, 2),
             "peak": 29.65, "unit": "T lane-instr/s", "frac": round(mul_instr / (acc_avg_ms * 1e-3) / 29.65e12, 4),
-            "work_items": int(items)}
+            "work_items": int(items),
+            "multiplier_instructions_per_mixed_addition": int(per_madd),
+            "multiplier_instructions_per_affine_start": int(per_start),
+            "valu_instructions_per_mixed_addition": valu_per_madd,
+            "counts_source": "metal-msm-gpu-acceleration_amd/isa_counts.json (tools/isa_counts.py over the compiler's "
+                             "assembly of the shipped k_accumulate.hip, written by the build)"}
     roofline["secondary"] = valu
 
     # ---- parity on every rank + CPU baseline (rank 0, single-GPU run only)
@@ -316,6 +331,8 @@ def main(argv=None):
             "config": {"workload": f"log_size={args.log_size}, {inst} instances per GPU, h2c BN254 G1 "
                                    f"(gpu_msm_h2c pipeline, window {window})",
                        "instances_per_gpu": inst, "log_size": args.log_size, "window_size": window,
+                       "inputs": "device-resident, device-generated (msm_amd_generate_instance) before the timed "
+                                 "region; nothing crosses PCIe inside it except the 96-byte results",
                        "parallelism": f"instance-sharded x{world}, "
                                       + ("RCCL all_gather of 96-byte results" if args.backend == "nccl" else
                                          "gloo all_gather of 96-byte results (REHEARSAL"

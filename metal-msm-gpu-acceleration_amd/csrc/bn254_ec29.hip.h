@@ -139,11 +139,13 @@ MSM_HD PtI pti_madd(const PtI& p, const AffI& q) {
   const fe29 P = Fq29::norm(Fq29::sub<K16E30>(U2, p.x));   // < 17.1 p
   const fe29 R = Fq29::norm(Fq29::sub<K8E30>(S2, p.y));    // <  9.1 p
   if (Fq29::maybe_zero(P, 18)) {
+    MSM_ISA_MARK("rare mixed_addition");
     if (Fq29::is_zero_exact(P)) {   // same x: either q == p (double) or q == -p (identity)
       if (Fq29::is_zero_exact(R)) return pti_double(pti_from_affi(q));
       return pti_identity();
     }
   }
+  MSM_ISA_MARK("resume mixed_addition");
   const fe29 PP = Fq29::sqr(P);
   const fe29 PPP = Fq29::mul(P, PP);
   const fe29 Q = Fq29::mul(p.x, PP);
@@ -167,11 +169,13 @@ MSM_HD PtI pti_mmadd(const fe29& px, const fe29& py, const AffI& q) {
   const fe29 P = Fq29::norm(Fq29::sub<K16E30>(q.x, px));   // < 17.1 p
   const fe29 R = Fq29::norm(Fq29::sub<K8E30>(q.y, py));    // < 12.1 p (q.y may be an un-normalised negation, py not)
   if (Fq29::maybe_zero(P, 18)) {
+    MSM_ISA_MARK("rare affine_start");
     if (Fq29::is_zero_exact(P)) {   // same x: either q == p (double) or q == -p (identity)
       if (Fq29::is_zero_exact(R)) return pti_double(pti_from_affi(q));
       return pti_identity();
     }
   }
+  MSM_ISA_MARK("resume affine_start");
   const fe29 PP = Fq29::sqr(P);
   const fe29 PPP = Fq29::mul(P, PP);
   const fe29 Q = Fq29::mul(px, PP);

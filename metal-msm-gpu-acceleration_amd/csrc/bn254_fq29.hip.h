@@ -54,6 +54,15 @@ MSM_HD fe29 pin_limbs(const fe29& a) {
   return r;
 }
 
+// A comment line in the generated assembly (no instruction): tools/isa_counts.py tallies the instructions between
+// marks to get the per-addition instruction counts of the shipped kernel (bench.py's second roofline).  Marks sit at
+// the first / last statement of a basic block, where they cannot hold back the scheduler.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MSM_ISA_MARK(name) asm volatile("; MSM_MARK " name)
+#else
+#define MSM_ISA_MARK(name) ((void)0)
+#endif
+
 enum KSel { K4E30 = 0, K8E30 = 1, K8E31 = 2, K16E30 = 3, K16E31 = 4 };
 
 struct Fq29 {
@@ -205,6 +214,104 @@ struct Fq29 {
     }
     r.l[8] = (uint32_t)t;
     return r;
+  }
+
+  // Two (or three) INDEPENDENT products in lockstep, product-scanning form: column k of every job is accumulated
+  // before column k + 1 of any, with the multiply-adds of the jobs alternating instruction by instruction.  One
+  // product-scanning chain is a string of dependent v_mad_u64_u32 (8.5 cycles from one to the next when a wave is
+  // alone: fq29_bench, 1741 cycles per multiplication at 1 wave/SIMD against 1107 at 4); two chains per wave and two
+  // waves per SIMD give the issue logic four independent streams -- what fips<> alone only gets at 4 waves/SIMD,
+  // which the accumulate kernel cannot have.  Against the column-parallel mul() this saves the 64-bit carry addition
+  // of every column (the chain starts FROM the carry) and the 17 x 2 live column registers.
+  // Job q: value = sum over its NPROD products x[q][r] * y[q][r]; SQUARE jobs pass x = 2a, y = a.
+  struct FipsJob {
+    const fe29* x[2];
+    const fe29* y[2];
+  };
+  template <int NJOBS, int NP0, bool SQ0, int NP1, bool SQ1, int NP2 = 0, bool SQ2 = false>
+  MSM_HD static void fips_multi(const FipsJob (&job)[NJOBS], fe29 (&r)[NJOBS]) {
+    constexpr int np[3] = {NP0, NP1, NP2};
+    constexpr bool sq[3] = {SQ0, SQ1, SQ2};
+    uint32_t m[NJOBS][9];
+    uint64_t t[NJOBS];
+    MSM_UNROLL for (int q = 0; q < NJOBS; ++q) t[q] = 0;
+    MSM_UNROLL for (int k = 0; k < 17; ++k) {
+      MSM_UNROLL for (int i = 0; i < 9; ++i) {
+        const int j = k - i;
+        MSM_UNROLL for (int q = 0; q < NJOBS; ++q) {
+          MSM_UNROLL for (int pr = 0; pr < 2; ++pr) {
+            if (pr < np[q] && j >= 0 && j < 9 && (!sq[q] || i < j)) mad64(t[q], job[q].x[pr]->l[i], job[q].y[pr]->l[j]);
+          }
+        }
+      }
+      MSM_UNROLL for (int q = 0; q < NJOBS; ++q) {
+        MSM_UNROLL for (int pr = 0; pr < 2; ++pr) {
+          if (pr < np[q] && sq[q] && (k & 1) == 0) mad64(t[q], job[q].y[pr]->l[k >> 1], job[q].y[pr]->l[k >> 1]);
+        }
+      }
+      MSM_UNROLL for (int i = 0; i < 9; ++i) {
+        const int j = k - i;
+        MSM_UNROLL for (int q = 0; q < NJOBS; ++q) {
+          if (i < k && j >= 1 && j < 9) mad64c(t[q], m[q][i], p(j));
+        }
+      }
+      MSM_UNROLL for (int q = 0; q < NJOBS; ++q) {
+        if (k < 9) {
+          m[q][k] = ((uint32_t)t[q] * INV) & MASK;
+          mad64c(t[q], m[q][k], p(0));
+        } else {
+          r[q].l[k - 9] = (uint32_t)t[q] & MASK;
+        }
+        t[q] >>= 29;
+      }
+    }
+    MSM_UNROLL for (int q = 0; q < NJOBS; ++q) r[q].l[8] = (uint32_t)t[q];
+  }
+  // (a * b, c * d) -- two multiplications side by side
+  MSM_HD static void mul_pair(const fe29& a_in, const fe29& b_in, const fe29& c_in, const fe29& d_in, fe29& ab, fe29& cd) {
+    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in), c = pin_limbs(c_in), d = pin_limbs(d_in);
+    const FipsJob jobs[2] = {{{&a, nullptr}, {&b, nullptr}}, {{&c, nullptr}, {&d, nullptr}}};
+    fe29 r[2];
+    fips_multi<2, 1, false, 1, false>(jobs, r);
+    ab = r[0];
+    cd = r[1];
+  }
+  // (a^2, b^2)
+  MSM_HD static void sqr_pair(const fe29& a_in, const fe29& b_in, fe29& aa, fe29& bb) {
+    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in);
+    fe29 a2, b2;
+    MSM_UNROLL for (int i = 0; i < 9; ++i) {
+      a2.l[i] = a.l[i] << 1;
+      b2.l[i] = b.l[i] << 1;
+    }
+    const FipsJob jobs[2] = {{{&a2, nullptr}, {&a, nullptr}}, {{&b2, nullptr}, {&b, nullptr}}};
+    fe29 r[2];
+    fips_multi<2, 1, true, 1, true>(jobs, r);
+    aa = r[0];
+    bb = r[1];
+  }
+  // (a * b + c * d, e * f) -- the shared-reduction double product next to a plain multiplication
+  MSM_HD static void mul2_mul_pair(const fe29& a_in, const fe29& b_in, const fe29& c_in, const fe29& d_in, const fe29& e_in,
+                                   const fe29& f_in, fe29& abcd, fe29& ef) {
+    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in), c = pin_limbs(c_in), d = pin_limbs(d_in), e = pin_limbs(e_in),
+               f = pin_limbs(f_in);
+    const FipsJob jobs[2] = {{{&a, &c}, {&b, &d}}, {{&e, nullptr}, {&f, nullptr}}};
+    fe29 r[2];
+    fips_multi<2, 2, false, 1, false>(jobs, r);
+    abcd = r[0];
+    ef = r[1];
+  }
+  // (a * b, c * d, e * f) -- three multiplications side by side
+  MSM_HD static void mul_triple(const fe29& a_in, const fe29& b_in, const fe29& c_in, const fe29& d_in, const fe29& e_in,
+                                const fe29& f_in, fe29& ab, fe29& cd, fe29& ef) {
+    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in), c = pin_limbs(c_in), d = pin_limbs(d_in), e = pin_limbs(e_in),
+               f = pin_limbs(f_in);
+    const FipsJob jobs[3] = {{{&a, nullptr}, {&b, nullptr}}, {{&c, nullptr}, {&d, nullptr}}, {{&e, nullptr}, {&f, nullptr}}};
+    fe29 r[3];
+    fips_multi<3, 1, false, 1, false, 1, false>(jobs, r);
+    ab = r[0];
+    cd = r[1];
+    ef = r[2];
   }
 
   // a*b*rho^-1 mod p (lazily reduced).  81 + 81 limb products, no carry instructions.

@@ -76,14 +76,18 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
         acc_affine = true;
       }
     } else if (acc_affine) {   // second point of the item (wave-uniform in practice): affine + affine, 4M + 2S
+      MSM_ISA_MARK("begin affine_start");
       const PtI sum = pti_mmadd(acc.x, acc.y, cur);
       if (!cur_is_id) {
         acc = sum;
         acc_affine = false;
       }
+      MSM_ISA_MARK("end");
     } else {
+      MSM_ISA_MARK("begin mixed_addition");
       const PtI sum = pti_madd(acc, cur);
       if (!cur_is_id) acc = sum;
+      MSM_ISA_MARK("end");
     }
   }
   if (size <= CH) {

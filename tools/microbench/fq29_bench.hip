@@ -21,6 +21,20 @@ __global__ void __launch_bounds__(256) k_op(const u256* in, u256* out) {
       if (VARIANT == 3) x = Fq29::norm(Fq29::add(x, y));
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = Fq29::to_ext(x);
+  } else if (VARIANT >= 6 && VARIANT <= 9) {
+    // two multiplications per trip: one after the other, or side by side in lockstep product-scanning chains
+    fe29 x = Fq29::from_ext(xe), y = Fq29::from_ext(ye), z = Fq29::from_ext(in[(threadIdx.x + 13) & 63]);
+#pragma unroll 1
+    for (int i = 0; i < ITER; ++i) {
+      fe29 a, b;
+      if (VARIANT == 6) { a = Fq29::mul(x, y); b = Fq29::mul(z, y); }
+      if (VARIANT == 7) Fq29::mul_pair(x, y, z, y, a, b);
+      if (VARIANT == 8) { a = Fq29::sqr(x); b = Fq29::sqr(z); }
+      if (VARIANT == 9) Fq29::sqr_pair(x, z, a, b);
+      x = a;
+      z = b;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = Fq29::to_ext(Fq29::norm(Fq29::add(x, z)));
   } else {
     Affine qa; qa.x = xe; qa.y = ye;           // not a curve point: timing only (no exceptional paths taken)
     const AffI q = affi_from_ext(qa);
@@ -62,6 +76,10 @@ int main() {
   run<1>("Fq29::sqr", din, dout, cus);
   run<2>("Fq29::sub+norm", din, dout, cus);
   run<3>("Fq29::add+norm", din, dout, cus);
+  run<6>("2 x mul", din, dout, cus);
+  run<7>("mul_pair", din, dout, cus);
+  run<8>("2 x sqr", din, dout, cus);
+  run<9>("sqr_pair", din, dout, cus);
   run<4>("pti_madd", din, dout, cus);
   run<5>("pti_add_nz", din, dout, cus);
   return 0;
