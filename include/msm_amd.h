@@ -408,7 +408,14 @@ enum {
   MSM_AMD_OP_H64_FP_ADD = 28,
   MSM_AMD_OP_H64_FP_SUB = 29,
   MSM_AMD_OP_H64_EC_ADD = 30,      /* Jacobian + Jacobian, 24 limbs each */
-  MSM_AMD_OP_H64_EC_DBL = 31
+  MSM_AMD_OP_H64_EC_DBL = 31,
+  /* field ops on internal limbs again (device and host): build options of the multiplication that were measured and
+     not shipped -- one Karatsuba level, lockstep product-scanning chains; operands / results as for op 14 */
+  MSM_AMD_OP_FP29_MUL_KARATSUBA = 32, /* a * b */
+  MSM_AMD_OP_FP29_LOCKSTEP_PAIR = 33, /* a * b + b * b        (two products side by side) */
+  MSM_AMD_OP_FP29_LOCKSTEP_MIX = 34,  /* 2 a b + 2 a^2 + b^2  (double product next to a product, squaring pair) */
+  MSM_AMD_OP_FP29_LOCKSTEP_TRIPLE = 35, /* a b + a^2 + b^2    (three products side by side) */
+  MSM_AMD_OP_FP29_MUL2_KARATSUBA = 36 /* 2 a b                (schoolbook + Karatsuba product, one reduction) */
 };
 int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count);
 /* The same operation bodies executed on the host CPU (no GPU needed): host-logic tests. */

@@ -24,11 +24,12 @@ POINT_BYTES = {POINT_H2C_AFFINE: 64, POINT_ARK_PROJECTIVE: 96, POINT_ARK_AFFINE:
  OP_FP_POW, OP_EC_ADD, OP_EC_MUL, OP_EC_MADD, OP_EC_DBL, OP_FP29_MUL, OP_FP29_SQR, OP_FP29_SUB_K4E30,
  OP_FP29_SUB_K8E30, OP_FP29_SUB_K8E31, OP_FP29_SUB_K16E30, OP_FP29_SUB_K16E31, OP_FP29_ROUNDTRIP, OP_EC29_MADD,
  OP_EC29_ADD, OP_EC29_MADD_CHAIN, OP_EC29_ADD_CHAIN, OP_EC29_MMADD, OP_H64_FP_MUL, OP_H64_FP_ADD, OP_H64_FP_SUB,
- OP_H64_EC_ADD, OP_H64_EC_DBL) = range(32)
+ OP_H64_EC_ADD, OP_H64_EC_DBL, OP_FP29_MUL_KARATSUBA, OP_FP29_LOCKSTEP_PAIR, OP_FP29_LOCKSTEP_MIX,
+ OP_FP29_LOCKSTEP_TRIPLE, OP_FP29_MUL2_KARATSUBA) = range(37)
 
 
 def op_is_point(op):
-    return 10 <= op <= 13 or 22 <= op <= 26 or op >= OP_H64_EC_ADD
+    return 10 <= op <= 13 or 22 <= op <= 26 or op in (OP_H64_EC_ADD, OP_H64_EC_DBL)
 
 # every symbol include/msm_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [

@@ -75,14 +75,36 @@ MSM_HD AffI affi_from_ext(const Affine& p) {
   return r;
 }
 
+// The identity is stored as x = 2^256 - 1, y = 0: a canonical coordinate is < p < 2^254, so ONE word tells the two
+// apart (affpacked_is_identity) where the unpacked form needs all 18 limbs (affi_is_identity).
 MSM_HD AffPacked affi_pack(const AffI& p) {   // p from affi_from_ext (multiplication outputs or exact zeros)
   AffPacked r;
+  if (affi_is_identity(p)) {
+    MSM_UNROLL for (int i = 0; i < 8; ++i) {
+      r.x.v[i] = 0xFFFFFFFFu;
+      r.y.v[i] = 0u;
+    }
+    return r;
+  }
   r.x = Fq29::pack_canonical(p.x);
   r.y = Fq29::pack_canonical(p.y);
   return r;
 }
+MSM_HD bool affpacked_is_identity(const AffPacked& p) { return p.x.v[7] == 0xFFFFFFFFu; }
 
-MSM_HD AffI affi_unpack(const AffPacked& p) {
+MSM_HD AffI affi_unpack(const AffPacked& p) {   // the identity comes back as exact zero limbs
+  AffI r;
+  if (affpacked_is_identity(p)) {
+    r.x = Fq29::zero();
+    r.y = Fq29::zero();
+    return r;
+  }
+  r.x = Fq29::unpack256(p.x);
+  r.y = Fq29::unpack256(p.y);
+  return r;
+}
+// The same without the identity test, for a caller that has made it (accumulate_kernel).
+MSM_HD AffI affi_unpack_finite(const AffPacked& p) {
   AffI r;
   r.x = Fq29::unpack256(p.x);
   r.y = Fq29::unpack256(p.y);
@@ -133,24 +155,54 @@ MSM_HD PtI pti_double(const PtI& p) {   // p not the identity
 // ---- fast paths -------------------------------------------------------------------------------------
 // p + q, p XYZZ (not identity), q affine (not identity).  madd-2008-s, 8M + 2S with the two products of Y3
 // sharing one Montgomery reduction (7 full multiplications + 1 product-only + 2 squarings).
-MSM_HD PtI pti_madd(const PtI& p, const AffI& q) {
+// `vanished` is set when the sum is the identity (q == -p); the caller tracks that state instead of testing limbs.
+// MSM_FQ29_LOCKSTEP: the independent products of the formula run side by side as lockstep product-scanning chains
+// (Fq29::fips_multi): (U2, S2), (PP, RR), (PPP, Q, ZZ3), (Y3, ZZZ3).
+MSM_HD PtI pti_madd(const PtI& p, const AffI& q, bool& vanished) {
+#if defined(MSM_FQ29_LOCKSTEP)
+  fe29 U2, S2;
+  Fq29::mul_pair(q.x, p.zz, q.y, p.zzz, U2, S2);
+#elif defined(MSM_FQ29_KARATSUBA)
+  const fe29 U2 = Fq29::mul_karatsuba(q.x, p.zz);
+  const fe29 S2 = Fq29::mul_karatsuba(q.y, p.zzz);
+#else
   const fe29 U2 = Fq29::mul(q.x, p.zz);
   const fe29 S2 = Fq29::mul(q.y, p.zzz);
+#endif
   const fe29 P = Fq29::norm(Fq29::sub<K16E30>(U2, p.x));   // < 17.1 p
   const fe29 R = Fq29::norm(Fq29::sub<K8E30>(S2, p.y));    // <  9.1 p
   if (Fq29::maybe_zero(P, 18)) {
     MSM_ISA_MARK("rare mixed_addition");
     if (Fq29::is_zero_exact(P)) {   // same x: either q == p (double) or q == -p (identity)
       if (Fq29::is_zero_exact(R)) return pti_double(pti_from_affi(q));
+      vanished = true;
       return pti_identity();
     }
   }
   MSM_ISA_MARK("resume mixed_addition");
+  PtI r;
+#if defined(MSM_FQ29_LOCKSTEP)
+  fe29 PP, RR, PPP, Q;
+  Fq29::sqr_pair(P, R, PP, RR);
+  Fq29::mul_triple(P, PP, p.x, PP, p.zz, PP, PPP, Q, r.zz);
+  r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.5 p
+  const fe29 T = Fq29::sub<K16E30>(Q, r.x);                                               // < 17.2 p
+  Fq29::mul2_mul_pair(R, T, p.y, Fq29::neg_wide(PPP), p.zzz, PPP, r.y, r.zzz);
+#elif defined(MSM_FQ29_KARATSUBA)
+  const fe29 PP = Fq29::sqr(P);
+  const fe29 PPP = Fq29::mul_karatsuba(P, PP);
+  const fe29 Q = Fq29::mul_karatsuba(p.x, PP);
+  const fe29 RR = Fq29::sqr(R);
+  r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.5 p
+  const fe29 T = Fq29::sub<K16E30>(Q, r.x);                                               // < 17.2 p
+  r.y = Fq29::mul2_karatsuba_second(R, T, p.y, Fq29::neg_wide(PPP));
+  r.zz = Fq29::mul_karatsuba(p.zz, PP);
+  r.zzz = Fq29::mul_karatsuba(p.zzz, PPP);
+#else
   const fe29 PP = Fq29::sqr(P);
   const fe29 PPP = Fq29::mul(P, PP);
   const fe29 Q = Fq29::mul(p.x, PP);
   const fe29 RR = Fq29::sqr(R);
-  PtI r;
   r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.5 p
   // T and -PPP stay un-normalised (limbs < 2^31 / 2^30.5): their partners R and Y1 in the double product are
   // normalised, and tools/fq29_bounds.py checks that no column of R*T + Y1*(-PPP) can reach 2^64
@@ -158,6 +210,7 @@ MSM_HD PtI pti_madd(const PtI& p, const AffI& q) {
   r.y = Fq29::mul2(R, T, p.y, Fq29::neg_wide(PPP));   // R*T - Y1*PPP in one reduction         // < 1.2 p
   r.zz = Fq29::mul(p.zz, PP);
   r.zzz = Fq29::mul(p.zzz, PPP);
+#endif
   return r;
 }
 
@@ -165,13 +218,14 @@ MSM_HD PtI pti_madd(const PtI& p, const AffI& q) {
 // from an affine base, ZZ = ZZZ = 1).  mmadd-2008-s: pti_madd without the four multiplications by ZZ1 / ZZZ1,
 // 4M + 2S.  (px, py) = p with px < 9.5 p, py < 6 p as in pti_madd; q.y may be a lazily negated value < 4 p.
 // The result obeys the same bounds as pti_madd's.
-MSM_HD PtI pti_mmadd(const fe29& px, const fe29& py, const AffI& q) {
+MSM_HD PtI pti_mmadd(const fe29& px, const fe29& py, const AffI& q, bool& vanished) {
   const fe29 P = Fq29::norm(Fq29::sub<K16E30>(q.x, px));   // < 17.1 p
   const fe29 R = Fq29::norm(Fq29::sub<K8E30>(q.y, py));    // < 12.1 p (q.y may be an un-normalised negation, py not)
   if (Fq29::maybe_zero(P, 18)) {
     MSM_ISA_MARK("rare affine_start");
     if (Fq29::is_zero_exact(P)) {   // same x: either q == p (double) or q == -p (identity)
       if (Fq29::is_zero_exact(R)) return pti_double(pti_from_affi(q));
+      vanished = true;
       return pti_identity();
     }
   }
@@ -187,6 +241,15 @@ MSM_HD PtI pti_mmadd(const fe29& px, const fe29& py, const AffI& q) {
   r.zz = PP;                                                                              // < 2.8 p
   r.zzz = PPP;
   return r;
+}
+
+MSM_HD PtI pti_madd(const PtI& p, const AffI& q) {
+  bool vanished = false;
+  return pti_madd(p, q, vanished);
+}
+MSM_HD PtI pti_mmadd(const fe29& px, const fe29& py, const AffI& q) {
+  bool vanished = false;
+  return pti_mmadd(px, py, q, vanished);
 }
 
 // p + q, both XYZZ, neither the identity.  add-2008-s, 12M + 2S.

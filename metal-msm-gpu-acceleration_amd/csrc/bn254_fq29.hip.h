@@ -57,6 +57,9 @@ MSM_HD fe29 pin_limbs(const fe29& a) {
 // A comment line in the generated assembly (no instruction): tools/isa_counts.py tallies the instructions between
 // marks to get the per-addition instruction counts of the shipped kernel (bench.py's second roofline).  Marks sit at
 // the first / last statement of a basic block, where they cannot hold back the scheduler.
+// (A mark tied to data -- an in/out operand of the empty asm -- would stay put, but it also costs the accumulate kernel
+// 18 VGPRs: measured 207 instead of 189.  Plain comments leave the code as it is; tools/isa_counts.py copes with them
+// drifting inside their block.)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MSM_ISA_MARK(name) asm volatile("; MSM_MARK " name)
 #else
@@ -333,6 +336,71 @@ struct Fq29 {
       }
       A[k] = s;
     }
+    return reduce_columns(A);
+  }
+
+  // One Karatsuba level over 3-limb blocks (a = A0 + A1 B + A2 B^2, B = 2^87): six 3 x 3 block products (54
+  // multiply-adds) instead of nine (81), paid for with 18 limb additions and 30 64-bit column subtractions
+  //   A0B0, A1B1, A2B2,  (A0+A1)(B0+B1) - A0B0 - A1B1,  (A0+A2)(B0+B2) - A0B0 - A2B2,  (A1+A2)(B1+B2) - A1B1 - A2B2
+  // Every column of a bracketed product dominates the same column of what is subtracted from it (the difference is
+  // the column of the cross terms), so the subtractions never borrow.  Operands must be normalised (limbs <= 2^29 + 8:
+  // a block sum then stays below 2^30 + 16 and a 3-term column below 2^62).
+  MSM_HD static void karatsuba_columns(const fe29& a, const fe29& b, uint64_t (&A)[17]) {
+    uint64_t P[3][5];   // A_i * B_i
+    MSM_UNROLL for (int blk = 0; blk < 3; ++blk) {
+      MSM_UNROLL for (int c = 0; c < 5; ++c) {
+        uint64_t s = 0;
+        MSM_UNROLL for (int i = 0; i < 3; ++i) {
+          const int j = c - i;
+          if (j >= 0 && j < 3) s += (uint64_t)a.l[3 * blk + i] * b.l[3 * blk + j];
+        }
+        P[blk][c] = s;
+      }
+    }
+    MSM_UNROLL for (int c = 0; c < 5; ++c) {   // A is ACCUMULATED into: the caller zeroes it or has another product there
+      A[c] += P[0][c];
+      A[12 + c] += P[2][c];
+    }
+    // cross terms of blocks (x, y) land at columns 3 (x + y) ..; the middle one starts from A1B1's columns
+    MSM_UNROLL for (int pr = 0; pr < 3; ++pr) {
+      const int x = pr == 2 ? 1 : 0, y = pr == 0 ? 1 : 2;
+      uint32_t sa[3], sb[3];
+      MSM_UNROLL for (int i = 0; i < 3; ++i) {
+        sa[i] = limb32(a.l[3 * x + i] + a.l[3 * y + i]);
+        sb[i] = limb32(b.l[3 * x + i] + b.l[3 * y + i]);
+      }
+      MSM_UNROLL for (int c = 0; c < 5; ++c) {
+        uint64_t s = (pr == 1) ? P[1][c] : 0;
+        MSM_UNROLL for (int i = 0; i < 3; ++i) {
+          const int j = c - i;
+          if (j >= 0 && j < 3) s += (uint64_t)sa[i] * sb[j];
+        }
+        s -= P[x][c];
+        s -= P[y][c];
+        A[3 * (x + y) + c] += s;
+      }
+    }
+  }
+  MSM_HD static fe29 mul_karatsuba(const fe29& a_in, const fe29& b_in) {
+    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in);
+    uint64_t A[17];
+    MSM_UNROLL for (int k = 0; k < 17; ++k) A[k] = 0;
+    karatsuba_columns(a, b, A);
+    return reduce_columns(A);
+  }
+  // a * b (schoolbook: b may be an un-normalised difference with limbs < 2^31) + c * d (Karatsuba), one reduction
+  MSM_HD static fe29 mul2_karatsuba_second(const fe29& a_in, const fe29& b_in, const fe29& c_in, const fe29& d_in) {
+    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in), c = pin_limbs(c_in), d = pin_limbs(d_in);
+    uint64_t A[17];
+    MSM_UNROLL for (int k = 0; k < 17; ++k) {
+      uint64_t s = 0;
+      MSM_UNROLL for (int i = 0; i < 9; ++i) {
+        const int j = k - i;
+        if (j >= 0 && j < 9) s += (uint64_t)a.l[i] * b.l[j];
+      }
+      A[k] = s;
+    }
+    karatsuba_columns(c, d, A);
     return reduce_columns(A);
   }
 

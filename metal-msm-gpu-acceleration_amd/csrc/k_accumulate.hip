@@ -35,7 +35,12 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
   const uint32_t cnt = min(size - lo, CH);
   const uint32_t* idx = sorted + (size_t)w * n + bucket_start[b] + lo;
   PtI acc = pti_identity();
-  bool acc_affine = false;   // acc was set from an affine base and nothing was added yet (ZZ = ZZZ = 1)
+  // What acc holds is tracked in a lane register instead of being read off its limbs every trip:
+  //   kEmpty  the identity (nothing added yet, or a sum that cancelled)
+  //   kOne    exactly one base, still affine (ZZ = ZZZ = 1): the next addition is affine + affine, 4M + 2S
+  //   kMany   a general XYZZ point: mixed additions, 8M + 2S
+  enum : uint32_t { kEmpty = 0, kOne = 1, kMany = 2 };
+  uint32_t state = kEmpty;
   // Software pipeline.  LOW_OCC (2 waves/SIMD) has ~20 spare VGPRs: the packed 64-byte record of point i + 1 is
   // gathered while point i is added, so a whole mixed addition (~5 us) hides the gather.  The 3-wave variant has
   // no registers to spare: it issues the gather at the top of the iteration and first consumes it after the
@@ -49,20 +54,22 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
   }
 #pragma unroll 1
   for (uint32_t i = 0; i < cnt; ++i) {
-    AffI cur;
+    AffPacked rec;
     if (LOW_OCC) {
-      cur = affi_unpack(pre);
+      rec = pre;
       if (i + 1 < cnt) {
         pre.x = load_u256(&bases[next_idx & 0x7FFFFFFFu].x);
         pre.y = load_u256(&bases[next_idx & 0x7FFFFFFFu].y);
       }
     } else {
-      cur = load_affi(&bases[cur_idx & 0x7FFFFFFFu]);
+      rec.x = load_u256(&bases[cur_idx & 0x7FFFFFFFu].x);
+      rec.y = load_u256(&bases[cur_idx & 0x7FFFFFFFu].y);
     }
-    const bool cur_is_id = affi_is_identity(cur);
     const bool negate = (cur_idx >> 31) != 0;   // negative digit: add -P (signed digits, see digits_kernel)
     cur_idx = next_idx;
     if (i + 2 < cnt) next_idx = idx[i + 2];
+    if (affpacked_is_identity(rec)) continue;   // an identity base adds nothing (one word tells: affi_pack)
+    AffI cur = affi_unpack_finite(rec);
     {
       // -y without the carry round (limbs < 2^30.5): y only ever multiplies the normalised ZZZ1, or enters the
       // lifted subtraction of pti_mmadd (bounds: tools/fq29_bounds.py)
@@ -70,24 +77,21 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
 #pragma unroll
       for (int l = 0; l < 9; ++l) cur.y.l[l] = negate ? ny.l[l] : cur.y.l[l];
     }
-    if (pti_is_identity(acc)) {
-      if (!cur_is_id) {
-        acc = pti_from_affi(cur);
-        acc_affine = true;
-      }
-    } else if (acc_affine) {   // second point of the item (wave-uniform in practice): affine + affine, 4M + 2S
+    if (state == kMany) {
+      MSM_ISA_MARK("begin mixed_addition");
+      bool vanished = false;
+      acc = pti_madd(acc, cur, vanished);
+      if (vanished) state = kEmpty;
+      MSM_ISA_MARK("end");
+    } else if (state == kOne) {   // second point of the item (wave-uniform in practice): affine + affine
       MSM_ISA_MARK("begin affine_start");
-      const PtI sum = pti_mmadd(acc.x, acc.y, cur);
-      if (!cur_is_id) {
-        acc = sum;
-        acc_affine = false;
-      }
+      bool vanished = false;
+      acc = pti_mmadd(acc.x, acc.y, cur, vanished);
+      state = vanished ? (uint32_t)kEmpty : (uint32_t)kMany;
       MSM_ISA_MARK("end");
     } else {
-      MSM_ISA_MARK("begin mixed_addition");
-      const PtI sum = pti_madd(acc, cur);
-      if (!cur_is_id) acc = sum;
-      MSM_ISA_MARK("end");
+      acc = pti_from_affi(cur);
+      state = kOne;
     }
   }
   if (size <= CH) {

@@ -2243,7 +2243,8 @@ static void test_op_widths(int op, size_t* wa, size_t* wb) {
 }
 
 int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count) {
-  if (!ctx || !a || !b || !out || count == 0 || op < 0 || op > kTestOpMax)
+  if (!ctx || !a || !b || !out || count == 0 || op < 0 || op > kTestOpMax ||
+      (op >= MSM_AMD_OP_H64_FP_MUL && op <= MSM_AMD_OP_H64_EC_DBL))
     return fail(ctx, MSM_AMD_INPUT_ERROR, "bad test_op arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -9,7 +9,7 @@ namespace msm_amd {
 
 // a, b, out: little-endian u256 arrays; element t uses 1 (integer/field ops) or 3 (points) consecutive u256.
 MSM_HD void run_test_op(int op, const u256* a, const u256* b, u256* out, uint32_t t) {
-  if (op <= 9 || (op >= 14 && op <= 21)) {
+  if (op <= 9 || (op >= 14 && op <= 21) || op >= 32) {
     const u256 x = a[t];
     const u256 y = b[t];
     u256 r = u256_zero();
@@ -38,6 +38,28 @@ MSM_HD void run_test_op(int op, const u256* a, const u256* b, u256* out, uint32_
           case 19: ri = Fq29::norm(Fq29::sub<K16E30>(xi, yi)); break;
           case 20: ri = Fq29::norm(Fq29::sub<K16E31>(xi, y3)); break;
           case 21: ri = Fq29::unpack256(Fq29::pack_canonical(xi)); break;   // incl. the 32-byte storage form
+          // build options measured and not shipped: same values as mul / mul2 / sqr
+          case 32: ri = Fq29::mul_karatsuba(xi, yi); break;
+          case 33: {   // lockstep product-scanning chains: (x*y, y*y) side by side, their sum checked
+            fe29 u, v;
+            Fq29::mul_pair(xi, yi, yi, yi, u, v);
+            ri = Fq29::norm(Fq29::add(u, v));
+            break;
+          }
+          case 34: {   // (x*y + y*x, x*x) and the squaring pair
+            fe29 u, v, w, z;
+            Fq29::mul2_mul_pair(xi, yi, yi, xi, xi, xi, u, v);
+            Fq29::sqr_pair(xi, yi, w, z);
+            ri = Fq29::norm(Fq29::add(Fq29::add(u, v), Fq29::add(w, z)));
+            break;
+          }
+          case 35: {   // three products side by side
+            fe29 u, v, w;
+            Fq29::mul_triple(xi, yi, xi, xi, yi, yi, u, v, w);
+            ri = Fq29::norm(Fq29::add(u, Fq29::add(v, w)));
+            break;
+          }
+          case 36: ri = Fq29::mul2_karatsuba_second(xi, yi, yi, xi); break;   // 2 x y
         }
         r = Fq29::to_ext(ri);
       }
@@ -119,7 +141,7 @@ MSM_HD void run_test_op(int op, const u256* a, const u256* b, u256* out, uint32_
   po[t] = r;
 }
 
-constexpr int kTestOpMax = 26;
-MSM_HD bool test_op_is_point(int op) { return (op >= 10 && op <= 13) || op >= 22; }
+constexpr int kTestOpMax = 36;   // 27..31 exist on the host only (msm_host.hip), 32..36 are field ops again
+MSM_HD bool test_op_is_point(int op) { return (op >= 10 && op <= 13) || (op >= 22 && op <= 26); }
 
 }  // namespace msm_amd

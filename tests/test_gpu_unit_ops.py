@@ -126,3 +126,27 @@ def test_ec29_device_matches_host_twin_and_oracle(cfg, msm_pkg):
 
     dev = cfg.test_op(msm_pkg.OP_EC29_MMADD, a, b, cnt)
     assert [decode_be32_affine(dev[24 * i:24 * i + 24]) for i in range(cnt)] == [expect(p, q) for p, q in cases]
+
+
+def test_unshipped_multiplication_variants_on_the_device(cfg, msm_pkg):
+    """Ops 32..36: one Karatsuba level and the lockstep product-scanning chains (inline-assembly multiply-adds on the
+    device), build options that were measured and not shipped -- same values as the shipped
+    multiplication, and the host-only ops 27..31 are refused by the device entry point."""
+    rng = random.Random(2936)
+    a = [rng.randrange(o.P) for _ in range(300)] + [0, 1, o.P - 1]
+    b = [rng.randrange(o.P) for _ in range(300)] + [o.P - 1, 0, o.P - 1]
+    cnt = len(a)
+    fa, fb = sum((fq_be32(x) for x in a), []), sum((fq_be32(x) for x in b), [])
+
+    def run(op):
+        flat = cfg.test_op(op, fa, fb, cnt)
+        return [be32_fq(flat[8 * i:8 * i + 8]) for i in range(cnt)]
+
+    P = o.P
+    assert run(msm_pkg.OP_FP29_MUL_KARATSUBA) == [x * y % P for x, y in zip(a, b)]
+    assert run(msm_pkg.OP_FP29_LOCKSTEP_PAIR) == [(x * y + y * y) % P for x, y in zip(a, b)]
+    assert run(msm_pkg.OP_FP29_LOCKSTEP_MIX) == [(2 * x * y + 2 * x * x + y * y) % P for x, y in zip(a, b)]
+    assert run(msm_pkg.OP_FP29_LOCKSTEP_TRIPLE) == [(x * y + x * x + y * y) % P for x, y in zip(a, b)]
+    assert run(msm_pkg.OP_FP29_MUL2_KARATSUBA) == [2 * x * y % P for x, y in zip(a, b)]
+    with pytest.raises(msm_pkg.MsmError):
+        cfg.test_op(msm_pkg.OP_H64_FP_MUL, fa, fb, cnt)

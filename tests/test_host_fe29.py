@@ -156,4 +156,18 @@ def test_host64_field_and_group_ops(msm_pkg):
     assert [decode_be32_affine(flat[24 * i:24 * i + 24]) for i in range(cnt)] == [o.aff_add(p, p) for p, _ in cases]
     assert flat == msm_pkg.test_op_host(msm_pkg.OP_EC_DBL, ja, jb, cnt)
     with pytest.raises(msm_pkg.MsmError):
-        msm_pkg.test_op_host(32, ja, jb, cnt)
+        msm_pkg.test_op_host(99, ja, jb, cnt)
+
+
+def test_unshipped_multiplication_variants_agree(msm_pkg):
+    """One Karatsuba level and the lockstep product-scanning chains (build options measured on the GPU and not shipped,
+    DESIGN.md section 7) compute the same field elements as the shipped multiplication -- host twins of ops 32..36."""
+    rng = random.Random(29)
+    a = [rng.randrange(o.P) for _ in range(64)] + [0, 1, o.P - 1]
+    b = [rng.randrange(o.P) for _ in range(64)] + [o.P - 1, 0, o.P - 1]
+    P = o.P
+    assert _run(msm_pkg, msm_pkg.OP_FP29_MUL_KARATSUBA, a, b) == [x * y % P for x, y in zip(a, b)]
+    assert _run(msm_pkg, msm_pkg.OP_FP29_LOCKSTEP_PAIR, a, b) == [(x * y + y * y) % P for x, y in zip(a, b)]
+    assert _run(msm_pkg, msm_pkg.OP_FP29_LOCKSTEP_MIX, a, b) == [(2 * x * y + 2 * x * x + y * y) % P for x, y in zip(a, b)]
+    assert _run(msm_pkg, msm_pkg.OP_FP29_LOCKSTEP_TRIPLE, a, b) == [(x * y + x * x + y * y) % P for x, y in zip(a, b)]
+    assert _run(msm_pkg, msm_pkg.OP_FP29_MUL2_KARATSUBA, a, b) == [2 * x * y % P for x, y in zip(a, b)]

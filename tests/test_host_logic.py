@@ -127,3 +127,18 @@ def test_cpu_dispatch_threshold_is_small(msm_pkg):
     instance to the CPU; here only sizes below the measured crossover (a handful of points) are computed on the host."""
     t = msm_pkg.lib().msm_amd_cpu_dispatch_below()
     assert 0 <= t <= 1024
+
+
+def test_build_wrote_the_instruction_counts_of_the_shipped_kernel():
+    """bench.py's second roofline reads metal-msm-gpu-acceleration_amd/isa_counts.json, which the build derives from the
+    compiler's assembly of k_accumulate.hip (tools/isa_counts.py): 8M + 2S with one shared reduction on 9 x 29-bit
+    limbs is 6 x 171 + 2 x 135 + 252 + 1 = 1549 multiplier instructions; the affine start 4M + 2S = 865, plus the 171 of
+    the mixed addition's first product when the compiler speculates it above the path split."""
+    import json
+    path = os.path.join(ROOT, "metal-msm-gpu-acceleration_amd", "isa_counts.json")
+    d = json.load(open(path))
+    assert 1500 <= d["multiplier_per_mixed_addition"] <= 1600
+    assert d["multiplier_per_affine_start"] in range(840, 1060)
+    k = d["kernels"]["low_occupancy_2_waves"]
+    assert k["mixed_addition"]["valu"] > k["mixed_addition"]["multiplier"] > k["affine_start"]["multiplier"]
+    assert "accumulate_kernelILb1E" in k["symbol"]

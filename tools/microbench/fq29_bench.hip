@@ -11,7 +11,7 @@ constexpr int ITER = 1000;
 template <int VARIANT>
 __global__ void __launch_bounds__(256) k_op(const u256* in, u256* out) {
   const u256 xe = in[threadIdx.x & 63], ye = in[(threadIdx.x + 7) & 63];
-  if (VARIANT <= 3) {
+  if (VARIANT <= 3 || VARIANT == 10) {
     fe29 x = Fq29::from_ext(xe), y = Fq29::from_ext(ye);
 #pragma unroll 1
     for (int i = 0; i < ITER; ++i) {
@@ -19,6 +19,7 @@ __global__ void __launch_bounds__(256) k_op(const u256* in, u256* out) {
       if (VARIANT == 1) x = Fq29::sqr(x);
       if (VARIANT == 2) x = Fq29::norm(Fq29::sub<K16E30>(y, x));
       if (VARIANT == 3) x = Fq29::norm(Fq29::add(x, y));
+      if (VARIANT == 10) x = Fq29::mul_karatsuba(x, y);
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = Fq29::to_ext(x);
   } else if (VARIANT >= 6 && VARIANT <= 9) {
@@ -76,6 +77,7 @@ int main() {
   run<1>("Fq29::sqr", din, dout, cus);
   run<2>("Fq29::sub+norm", din, dout, cus);
   run<3>("Fq29::add+norm", din, dout, cus);
+  run<10>("mul_karatsuba", din, dout, cus);
   run<6>("2 x mul", din, dout, cus);
   run<7>("mul_pair", din, dout, cus);
   run<8>("2 x sqr", din, dout, cus);
