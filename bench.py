@@ -126,6 +126,9 @@ def main(argv=None):
 
     m = importlib.import_module(PKG)
     cfg = m.setup_metal_state(gpu_index)           # fails loudly without a gfx950 device
+    # this rank's host threads (submission, Horner passes, later its parity check) stay on the CPUs local to its GPU
+    # when sysfs tells which those are (threads started from here on inherit the mask); never an error
+    numa_pinned = (world > 1) and m.lib().msm_amd_pin_thread_to_device(gpu_index) == 0
     if args.window:
         cfg.set_window_size(args.window)
     n = 1 << args.log_size
@@ -325,6 +328,7 @@ def main(argv=None):
             "dtype": "u32x8 (256-bit Montgomery integer)",
             "data": "synthetic",
             "rccl_ranks_seen": ranks_seen,
+            "ranks_pinned_to_gpu_numa_node": bool(numa_pinned),
             "collective": "rccl" if args.backend == "nccl" else "gloo (rehearsal, not RCCL)",
             "parity": ("bit-exact vs the CPU oracle on every rank's own instances" if not args.no_cpu_baseline
                        else "not checked in this run (--no-cpu-baseline)"),
@@ -385,6 +389,25 @@ def drop_in_caller_figures(m, cfg, h_sc, h_pts, n, inst, expect):
     res["e2e_host_slices_MSM_per_s"] = round(inst * reps / dt, 2)
     res["e2e_host_slices_note"] = (f"msm_amd_msm_batch on pageable host buffers: {inst} x 2^{n.bit_length() - 1} "
                                    f"points, 96 MiB per instance uploaded inside the timed region")
+    # the SAME call with the library's bases cache switched on (msm_amd_set_bases_cache: opt-in, no API change for
+    # the caller): the converted bases of every slice stay resident, only the 32 MiB of scalars cross PCIe
+    cfg.set_bases_cache(64 * n * inst * 2)
+    cfg.msm_batch(h_sc, h_pts, ns)                               # fills the cache (misses)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        outs = cfg.msm_batch(h_sc, h_pts, ns)
+    dt = time.perf_counter() - t0
+    if outs != expect:
+        raise SystemExit("PARITY FAILURE: cached host-slice batch differs from the device-resident results")
+    st = cfg.bases_cache_stats()
+    if st["hits"] != inst * reps or st["misses"] != inst:
+        raise SystemExit(f"bases cache did not behave as expected: {st}")
+    res["e2e_host_slices_bases_cache_MSM_per_s"] = round(inst * reps / dt, 2)
+    res["e2e_host_slices_bases_cache_note"] = (
+        "the same msm_amd_msm_batch call on the same pageable slices with msm_amd_set_bases_cache (opt-in): converted "
+        f"bases stay resident ({st['bytes'] >> 20} MiB), every call re-hashes ~2 k sampled records per slice; cache-off "
+        "figure: e2e_host_slices_MSM_per_s")
+    cfg.set_bases_cache(0)
     # the same call on buffers the caller page-locked once (msm_amd_host_register): DMA uploads
     for b in h_sc + h_pts:
         cfg.host_register(b)
@@ -396,6 +419,17 @@ def drop_in_caller_figures(m, cfg, h_sc, h_pts, n, inst, expect):
     if outs != expect:
         raise SystemExit("PARITY FAILURE: registered host-slice batch differs from the device-resident results")
     res["e2e_host_slices_registered_MSM_per_s"] = round(inst * reps / dt, 2)
+    # registered slices AND the bases cache: scalars by DMA, bases resident
+    cfg.set_bases_cache(64 * n * inst * 2)
+    cfg.msm_batch(h_sc, h_pts, ns)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        outs = cfg.msm_batch(h_sc, h_pts, ns)
+    dt = time.perf_counter() - t0
+    if outs != expect:
+        raise SystemExit("PARITY FAILURE: cached registered batch differs from the device-resident results")
+    res["e2e_host_slices_registered_bases_cache_MSM_per_s"] = round(inst * reps / dt, 2)
+    cfg.set_bases_cache(0)
     for b in h_pts:
         cfg.host_unregister(b)
     # bases resident (converted once: an SRS), scalars from registered host memory: 32 MiB per instance over PCIe
@@ -463,7 +497,16 @@ def drop_in_caller_figures(m, cfg, h_sc, h_pts, n, inst, expect):
             ts.append(time.perf_counter() - t0)
         return round(statistics.median(ts) * 1e3, 3)
 
+    def with_cache(fn, k):
+        cfg.set_bases_cache(64 * k * 2)
+        try:
+            return fn(k)
+        finally:
+            cfg.set_bases_cache(0)
+
     res["single_call_ms"] = {"msm_best_host_2^20": lone_best(min(n, 1 << 20)),
+                             "msm_best_host_2^20_bases_cache": with_cache(lone_best, min(n, 1 << 20)),
+                             "gpu_msm_h2c_host_2^20_bases_cache": with_cache(lone, min(n, 1 << 20)),
                              "gpu_msm_h2c_host_2^20": lone(min(n, 1 << 20)),
                              "gpu_msm_h2c_host_registered_2^20": lone_registered(min(n, 1 << 20)),
                              "gpu_msm_h2c_host_2^18": lone(min(n, 1 << 18)),
