@@ -497,6 +497,27 @@ def drop_in_caller_figures(m, cfg, h_sc, h_pts, n, inst, expect):
             ts.append(time.perf_counter() - t0)
         return round(statistics.median(ts) * 1e3, 3)
 
+    # The same host-slice batch through the C++ CLI in a child process: no PyTorch in that process, so it binds the
+    # SYSTEM HIP runtime (7.2), whose staged pageable copies overlap kernels -- what a Rust caller of the C ABI gets.
+    # (This process is bound to the HIP 7.0 runtime inside the PyTorch wheel, where they serialise.)
+    def cli(extra):
+        import subprocess
+        exe = os.path.join(ROOT, "metal-msm-gpu-acceleration_amd", "gpu_profiler")
+        cmd = [exe, str(n.bit_length() - 1), str(inst), "gpu", "5", "true", "--warmup", "1", "--json"] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            return round(1e3 / d["avg_instance_ms"], 2)
+        except Exception as e:   # noqa: BLE001
+            return f"unavailable ({type(e).__name__})"
+
+    res["cli_system_runtime"] = {
+        "e2e_host_slices_MSM_per_s": cli([]),
+        "e2e_host_slices_bases_cache_MSM_per_s": cli(["--bases-cache", str((64 * n * inst * 2) >> 20)]),
+        "note": f"gpu_profiler {n.bit_length() - 1} {inst} gpu 5 true [--bases-cache]: msm_amd_msm_batch on pageable host "
+                "slices from a process without PyTorch (system HIP runtime); instances of the same seeds, results not "
+                "re-checked here (tests/test_gpu_profiler_cli.py, tests/test_gpu_bases_cache.py do)"}
+
     def with_cache(fn, k):
         cfg.set_bases_cache(64 * k * 2)
         try:
