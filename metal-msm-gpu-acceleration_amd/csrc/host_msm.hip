@@ -13,6 +13,10 @@
 //            multiplications each -- no pathological case).  (Tasks over bucket RANGES instead of point groups --
 //            disjoint bucket sets, nothing to merge -- were measured too: 18-24 ms against 15.7-17.5 ms at 2^16
 //            points on 16 threads, the strided reads of the points cost more than the merge.)
+//            On hosts with AVX-512 IFMA (Zen 4 / 5, Ice Lake and later: CPUID-checked, MSM_AMD_HOST_NO_IFMA=1 turns it
+//            off) the batched additions run eight per vector in radix 2^52 (host_ifma.cpp: 1.7 ns per field
+//            multiplication against 10 ns), a collision waits for the next batch instead of paying a Jacobian
+//            addition, and the batch is half the bucket count: 9.2 instead of 13.3 ms at 2^16 points on 16 threads.
 //   phase 2  tasks (window, bucket segment): running sums over the segment across all groups, two interleaved chains,
 //            sum_b (b + 1) B_b = sum_seg [ sum_{b in seg} (b - lo + 1) B_b  +  lo * sum_{b in seg} B_b ]
 //   phase 3  Horner over the windows (one thread; 254 doublings)
@@ -34,6 +38,7 @@
 #include "device_common.hip.h"
 #include "launch.h"
 #include "host_fq64.h"
+#include "host_ifma.h"
 
 namespace msm_amd {
 
@@ -120,11 +125,12 @@ struct BucketSet {
   bool any_side = false;
 };
 
-constexpr int kBatch = 512;
+constexpr int kBatch = 1024;
+static_assert(kBatch <= ifma::kMaxBatch, "the vector path's scratch holds a whole batch");
 
 struct Pending {
   uint32_t bucket[kBatch];
-  Aff pt[kBatch];
+  alignas(64) Aff pt[kBatch];
   Fe den[kBatch], pre[kBatch];
   uint8_t kind[kBatch];   // 0 = generic addition, 1 = doubling, 2 = P + (-P)
   int count = 0;
@@ -245,6 +251,146 @@ void fill_buckets(BucketSet& B, Pending& q, const int16_t* digits, const Aff* po
   flush(B, q);
 }
 
+// ---- the same phase on AVX-512 IFMA (host_ifma.cpp): eight additions per vector -------------------------------------
+// Bucket and point coordinates live in the vector code's Montgomery domain (Q = 2^260 instead of R = 2^256) as
+// canonical 4 x u64 integers while a task fills its buckets; `points_q` is the whole point array converted once per
+// MSM, the task's buckets are converted back before phase 2 reads them.  The shared inversion stays scalar: the eight
+// chain totals of a batch are inverted together by Montgomery's trick on host_fq64.h.
+struct IfmaState {
+  ifma::Scratch scratch;
+  uint32_t pt_idx[kBatch];              // the batch's points: index into points_q, bit 31 = negated
+  std::vector<uint32_t> retry, again;   // points waiting for the next batch (fill_buckets_ifma)
+  Fe to_q;   // 2^264 mod p as an R-domain operand: mul(R^2 / X, to_q) = Q^2 / X
+};
+
+Fe pow2_mod_p(unsigned k) {   // 2^k mod p as a plain integer below p
+  Fe v;
+  std::memset(&v, 0, sizeof v);
+  v.v[0] = 1;
+  for (unsigned i = 0; i < k; ++i) v = h64::add(v, v);
+  return v;
+}
+
+void flush_ifma(BucketSet& B, Pending& q, IfmaState& st, const Aff* points_q) {
+  if (q.count == 0) return;
+  uint64_t totals[8][4], inv[8][4];
+  ifma::forward((const uint64_t*)B.aff.data(), q.bucket, (const uint64_t*)points_q, st.pt_idx, q.count, st.scratch, totals);
+  // 1 / totals[k] in the Q domain: with X = totals[k] read as an R-domain element, inv(X) = R^2 / X and
+  // mul(R^2 / X, 2^264) = Q^2 / X = (T Q)^-1 Q^2 = T^-1 Q.  One inversion for the eight of them.
+  Fe x[8], pre[8];
+  for (int k = 0; k < 8; ++k) {
+    std::memcpy(&x[k], totals[k], 32);
+    pre[k] = k ? h64::mul(pre[k - 1], x[k]) : x[k];
+  }
+  Fe run = h64::inv(pre[7]);
+  for (int k = 7; k >= 0; --k) {
+    const Fe xi = k ? h64::mul(run, pre[k - 1]) : run;
+    if (k) run = h64::mul(run, x[k]);
+    const Fe r = h64::mul(xi, st.to_q);
+    std::memcpy(inv[k], &r, 32);
+  }
+  ifma::backward((uint64_t*)B.aff.data(), q.bucket, q.count, st.scratch, inv);
+  q.count = 0;
+}
+
+// fill_buckets with the batched additions on the vector unit.  `points` (R domain) still feeds the Jacobian side
+// accumulators; `points_q` (Q domain) feeds the affine buckets.  A point whose x equals its bucket's current x (the
+// same point again, or its negative) goes to the side accumulator too -- jmadd resolves doubling and cancellation --
+// so every addition in a batch is a generic one.
+void fill_buckets_ifma(BucketSet& B, Pending& q, IfmaState& st, const int16_t* digits, const Aff* points, const Aff* points_q,
+                       size_t lo, size_t hi, uint32_t nbuckets, int batch) {
+  B.aff.assign(nbuckets, Aff{});
+  B.full.assign(nbuckets, 0);
+  B.stamp.assign(nbuckets, 0u);
+  B.side.clear();
+  B.any_side = false;
+  uint32_t batch_id = 1;
+  q.count = 0;
+  auto to_side = [&](uint32_t b, const Aff& src, bool negate) {
+    if (!B.any_side) {
+      B.side.resize(nbuckets);
+      std::memset((void*)B.side.data(), 0, nbuckets * sizeof(Jac));   // z = 0: identity
+      B.any_side = true;
+    }
+    Aff p = src;
+    if (negate) p.y = fe_neg(p.y);
+    B.side[b] = jmadd(B.side[b], p);
+  };
+  // A point whose bucket already has an addition pending in this batch WAITS for the next batch (st.retry) instead of
+  // paying a Jacobian addition; when the waiting list is full, or a batch drew less than an eighth of its additions
+  // from a non-empty list (skewed digits: everything wants the same few buckets), the rest goes to the Jacobian side
+  // accumulators after all.
+  std::vector<uint32_t>& retry = st.retry;
+  std::vector<uint32_t>& again = st.again;
+  retry.clear();
+  again.clear();
+  const size_t retry_cap = (size_t)batch;
+  auto add_one = [&](uint32_t i, bool may_wait) {
+    const int32_t d = digits[i];
+    const Aff& src = points[i];
+    const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+    if (B.stamp[b] == batch_id) {
+      if (may_wait && retry.size() < retry_cap) retry.push_back(i);
+      else to_side(b, src, d < 0);
+      return;
+    }
+    const Aff& pq = points_q[i];
+    if (!B.full[b]) {
+      B.aff[b] = pq;
+      if (d < 0) B.aff[b].y = fe_neg(pq.y);
+      B.full[b] = 1;
+      return;
+    }
+    if (fe_eq(B.aff[b].x, pq.x)) {   // same x: doubling or cancellation -- not an affine chord addition
+      to_side(b, src, d < 0);
+      return;
+    }
+    B.stamp[b] = batch_id;
+    q.bucket[q.count] = b;
+    st.pt_idx[q.count] = i | (d < 0 ? 0x80000000u : 0u);   // the vector code gathers and negates the point itself
+    ++q.count;
+  };
+  size_t i = lo;
+  for (;;) {
+    const size_t waiting = again.size();
+    int from_waiting = 0;
+    while (q.count < batch) {
+      if (!again.empty()) {
+        const int before = q.count;
+        const uint32_t idx = again.back();
+        again.pop_back();
+        add_one(idx, true);
+        from_waiting += q.count - before;
+      } else if (i < hi) {
+        const uint32_t idx = (uint32_t)i++;
+        const int32_t d = digits[idx];
+        if (d == 0) continue;
+        const Aff& src = points[idx];
+        if (h64::is_zero(src.x) && h64::is_zero(src.y)) continue;   // affine identity (0, 0)
+        add_one(idx, true);
+      } else {
+        break;
+      }
+    }
+    if (waiting >= 8 && (size_t)from_waiting * 8 < waiting) {   // the waiting list is not draining: skew
+      for (uint32_t idx : again) add_one(idx, false);
+      again.clear();
+      for (uint32_t idx : retry) {
+        const int32_t d = digits[idx];
+        to_side((uint32_t)(d < 0 ? -d : d) - 1, points[idx], d < 0);
+      }
+      retry.clear();
+    }
+    if (q.count == 0 && again.empty() && retry.empty() && i >= hi) break;
+    flush_ifma(B, q, st, points_q);
+    ++batch_id;
+    for (uint32_t idx : retry) again.push_back(idx);   // `again` may still hold entries when the batch filled up first
+    retry.clear();
+  }
+  // back to the R domain for phase 2 (empty slots are converted along; nobody reads them)
+  ifma::convert((const uint64_t*)B.aff.data(), (uint64_t*)B.aff.data(), (size_t)nbuckets * 2, 1);
+}
+
 // One phase-2 task: sum_{b in [lo, hi)} (b + 1) B_b where B_b is the sum over the window's point groups, by running
 // sums -- as TWO interleaved chains (upper and lower half of the segment): a running sum is a string of dependent
 // field multiplications (bound by the multiplier's latency), two independent ones in one loop overlap in the
@@ -283,23 +429,30 @@ Jac reduce_segment(const BucketSet* groups, uint32_t n_groups, uint32_t lo, uint
 // Measured on an EPYC 9575F, 16 threads, 2^16 points (`gpu_profiler 16 1 cpu 5`, profiles/r03_cpu_msm_sweep.txt):
 // c = 11 with 2 groups (48 tasks) 13.4 ms, c = 12 / 2 groups (44 tasks) 13.9, c = 13 / 4 groups (80 tasks) 14.3,
 // c = 13 / 2 groups (40 tasks) 15.6 -- the order this model gives.
+// One batched-affine addition on the vector unit costs about as much as 1.8 scalar multiplications (6 vector
+// multiplications + 6 exact subtractions per 8 additions, gathers and stores).
+constexpr double kVecAdd = 1.8;
+
 struct Choice {
   uint32_t c;
   uint32_t groups;   // point groups per window (phase-1 tasks = windows x groups)
   int batch;         // 0 = Jacobian accumulators only
 };
-int batch_for(uint32_t c, size_t points_per_task) {
-  const int batch = (int)std::min<size_t>(kBatch, ((size_t)1 << (c - 1)) / 4);
+int batch_for(uint32_t c, size_t points_per_task, bool vec = false) {
+  // scalar path: a quarter of the buckets (a collision costs a Jacobian addition); vector path: half of them (a
+  // collision only waits for the next batch)
+  const size_t nbk = (size_t)1 << (c - 1);
+  const int batch = (int)std::min<size_t>(vec ? kBatch : kBatch / 2, vec ? nbk / 2 : nbk / 4);
   if (batch < 8 || points_per_task < (size_t)4 * batch) return 0;
-  const double nb = (double)(1u << (c - 1));
-  const double cost = 6.0 + 384.0 / batch + 11.0 * batch / (2.0 * nb);
+  const double nb = (double)nbk;
+  const double cost = vec ? kVecAdd + 384.0 / batch : 6.0 + 384.0 / batch + 11.0 * batch / (2.0 * nb);
   return cost < 11.0 ? batch : 0;
 }
 uint32_t segments_for(uint32_t c, uint32_t groups, int threads) {   // phase-2 tasks per window, >= 32 buckets each
   const uint32_t half = 1u << (c - 1);
   return threads <= 1 ? 1u : std::max(1u, std::min(groups, half / 32 ? half / 32 : 1u));
 }
-Choice window_for(size_t n, int threads) {
+Choice window_for(size_t n, int threads, bool vec = false) {
   if (n < 32) return {3, 1, 0};   // the reference's policy for tiny instances (msm.rs:137-138)
   Choice best{4, 1, 0};
   double best_cost = 1e300;
@@ -309,8 +462,8 @@ Choice window_for(size_t n, int threads) {
     const double nb = (double)(1u << (c - 1));
     for (uint32_t groups = 1; groups <= max_groups; ++groups) {
       if (groups > 1 && n / groups < 256) break;
-      const int batch = batch_for(c, n / groups);
-      const double add = batch ? 6.0 + 384.0 / batch + 11.0 * batch / (2.0 * nb) : 11.0;
+      const int batch = batch_for(c, n / groups, vec);
+      const double add = !batch ? 11.0 : (vec ? kVecAdd + 384.0 / batch : 6.0 + 384.0 / batch + 11.0 * batch / (2.0 * nb));
       const uint32_t segs = segments_for(c, groups, threads);
       const double rounds1 = std::ceil((double)W * groups / threads), rounds2 = std::ceil((double)W * segs / threads);
       const double cost = rounds1 * ((double)n / groups) * add + rounds2 * (nb / segs) * 1.3 * (11.0 * groups + 16.0);
@@ -325,7 +478,8 @@ Choice window_for(size_t n, int threads) {
 
 Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n, int threads) {
   const int T = std::max(1, std::min<int>(threads, (int)std::min<size_t>((n + 63) / 64, 256)));
-  Choice choice = window_for(n, T);
+  const bool vec = ifma::available() && std::getenv("MSM_AMD_HOST_NO_IFMA") == nullptr;
+  Choice choice = window_for(n, T, vec);
   if (const char* e = std::getenv("MSM_AMD_HOST_WINDOW")) {   // experiments (tools/dbg/cpu_sweep.sh)
     const int v = std::atoi(e);
     if (v >= 3 && v <= 15) choice.c = (uint32_t)v;
@@ -335,13 +489,16 @@ Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n,
     if (v >= 1 && v <= 64) choice.groups = (uint32_t)v;
   }
   if (std::getenv("MSM_AMD_HOST_WINDOW") || std::getenv("MSM_AMD_HOST_GROUPS"))
-    choice.batch = batch_for(choice.c, n / choice.groups);
+    choice.batch = batch_for(choice.c, n / choice.groups, vec);
+  const bool use_vec = vec && choice.batch != 0;
   const uint32_t c = choice.c, groups = choice.groups;
   const uint32_t W = 254 / c + 1;
   const uint32_t half = 1u << (c - 1);   // buckets per window: slot b <-> digit magnitude b + 1
   const uint32_t segs = segments_for(c, groups, T);   // phase-2 tasks per window
   const uint32_t seg_len = (half + segs - 1) / segs;
   std::vector<int16_t> digits((size_t)W * n);
+  std::vector<Aff> points_q(use_vec ? n : 0);   // the points in the vector code's Montgomery domain
+  const Fe to_q = pow2_mod_p(264);
   std::vector<BucketSet> sets((size_t)W * groups);
   std::vector<Jac> part((size_t)W * segs);
   std::atomic<size_t> next0{0}, next1{0}, next2{0};
@@ -351,9 +508,9 @@ Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n,
   const auto t_begin = std::chrono::steady_clock::now();
   auto stamp = [&](const char* what) {
     if (trace)
-      std::fprintf(stderr, "host_msm: %-8s %8.3f ms (n=%zu c=%u W=%u groups=%u segs=%u batch=%d T=%d)\n", what,
+      std::fprintf(stderr, "host_msm: %-8s %8.3f ms (n=%zu c=%u W=%u groups=%u segs=%u batch=%d T=%d ifma=%d)\n", what,
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), n, c, W,
-                   groups, segs, choice.batch, T);
+                   groups, segs, choice.batch, T, (int)use_vec);
   };
   auto worker = [&](int tid) {
     // ---- phase 0: digits
@@ -382,19 +539,26 @@ Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n,
           digits[(size_t)w * n + i] = (int16_t)d;
         }
       }
+      if (use_vec) ifma::convert((const uint64_t*)(points + lo), (uint64_t*)(points_q.data() + lo), (hi - lo) * 2, 0);
     }
     barrier.wait();
     if (tid == 0) stamp("digits");
     // ---- phase 1: tasks (window, point group)
     {
       Pending* q = new Pending();
+      IfmaState* vs = use_vec ? new IfmaState() : nullptr;
+      if (vs) vs->to_q = to_q;
       for (;;) {
         const size_t t = next1.fetch_add(1, std::memory_order_relaxed);
         if (t >= (size_t)W * groups) break;
         const uint32_t w = (uint32_t)(t / groups), g = (uint32_t)(t % groups);
-        fill_buckets(sets[t], *q, &digits[(size_t)w * n], points, n * g / groups, n * (g + 1) / groups, half,
-                     choice.batch);
+        const size_t p_lo = n * g / groups, p_hi = n * (g + 1) / groups;
+        if (use_vec)
+          fill_buckets_ifma(sets[t], *q, *vs, &digits[(size_t)w * n], points, points_q.data(), p_lo, p_hi, half, choice.batch);
+        else
+          fill_buckets(sets[t], *q, &digits[(size_t)w * n], points, p_lo, p_hi, half, choice.batch);
       }
+      delete vs;
       delete q;
     }
     barrier.wait();

@@ -111,3 +111,39 @@ def test_gpu_profiler_cpu_mode_needs_no_gpu():
     x, _y = o.decode_jacobian_mont_le(want)
     # result0_x_le_hex is the Montgomery x of the normalised result
     assert bytes.fromhex(d["result0_x_le_hex"]) == o.int_to_le_bytes32(o.fq_to_mont(x))
+
+
+def test_host_msm_skew_at_a_size_that_uses_the_batched_paths(msm_pkg):
+    """2^15 points (batched-affine additions, on AVX-512 IFMA where the host has it): all scalars equal -- every point of
+    a window wants ONE bucket, the waiting list does not drain and the Jacobian accumulators take over; all points
+    equal -- every addition in a bucket is a doubling; half the points the negatives of the other half."""
+    n = 1 << 15
+    pts, sc = co.gen_instance(o.SEED_BASE + 1515, n)
+    sc_eq = sc[:32] * n
+    assert _same(msm_pkg.host_msm(sc_eq, pts, n, 4), co.msm_best(sc_eq, pts, n))
+    pts_eq = pts[:64] * n
+    assert _same(msm_pkg.host_msm(sc, pts_eq, n, 4), co.msm_best(sc, pts_eq, n))
+    half = n // 2
+    neg = bytearray(pts[:64 * half])
+    for i in range(half):
+        y = int.from_bytes(neg[64 * i + 32:64 * i + 64], "little")
+        neg[64 * i + 32:64 * i + 64] = ((o.P - y) % o.P).to_bytes(32, "little")
+    both = pts[:64 * half] + bytes(neg)
+    sc2 = sc[:32 * half] * 2                      # k_i P_i + k_i (-P_i) = O for every i
+    assert msm_pkg.host_msm(sc2, both, n, 4)[64:] == bytes(32)
+    sc3 = sc[:32 * half] + sc[32 * half:]         # different scalars on the negatives: a generic answer
+    assert _same(msm_pkg.host_msm(sc3, both, n, 3), co.msm_best(sc3, both, n))
+
+
+def test_host_msm_scalar_and_vector_paths_agree(msm_pkg):
+    """MSM_AMD_HOST_NO_IFMA=1 forces the MULX / ADX path on a host that has AVX-512 IFMA: same bytes either way."""
+    import os
+    n = 1 << 14
+    pts, sc = co.gen_instance(o.SEED_BASE + 1414, n)
+    a = msm_pkg.host_msm(sc, pts, n, 3)
+    os.environ["MSM_AMD_HOST_NO_IFMA"] = "1"
+    try:
+        b = msm_pkg.host_msm(sc, pts, n, 3)
+    finally:
+        del os.environ["MSM_AMD_HOST_NO_IFMA"]
+    assert a == b and _same(a, co.msm_best(sc, pts, n))

@@ -30,13 +30,37 @@ def main():
         pb, sb = co.gen_instance(o.SEED_BASE + 9000 + n, n)
         pool[n] = (dp, ds, o.decode_jacobian_mont_le(co.msm_best(sb, pb, n)))
         host[n] = (pb, sb)
+    # one instance built to hit the rare paths of the accumulate kernel in EVERY window: (k, P) next to (k, -P) (the sum
+    # of a bucket vanishes: lane state back to "empty"), (k, P) twice (doubling), identity bases, zero scalars
+    n_sp = 4097
+    pb, sb = bytearray(host[n_sp][0]), bytearray(host[n_sp][1])
+    for i in range(0, 128, 2):
+        x, y = pb[64 * i:64 * i + 32], int.from_bytes(pb[64 * i + 32:64 * i + 64], "little")
+        if i < 64:   # -P: y -> p - y in Montgomery form is (p - y_mont) as well
+            pb[64 * (i + 1):64 * (i + 1) + 64] = bytes(x) + ((o.P - y) % o.P).to_bytes(32, "little")
+        else:
+            pb[64 * (i + 1):64 * (i + 1) + 64] = pb[64 * i:64 * i + 64]
+        sb[32 * (i + 1):32 * (i + 1) + 32] = sb[32 * i:32 * i + 32]
+    for i in rng.sample(range(128, n_sp), 30):
+        pb[64 * i:64 * i + 64] = bytes(64)
+    for i in rng.sample(range(128, n_sp), 30):
+        sb[32 * i:32 * i + 32] = bytes(32)
+    pb, sb = bytes(pb), bytes(sb)
+    special = -n_sp                                   # key of the special instance in pool / host
+    dp, ds = cfg.alloc(64 * n_sp), cfg.alloc(32 * n_sp)
+    cfg.to_device(dp, pb)
+    cfg.to_device(ds, sb)
+    pool[special] = (dp, ds, o.decode_jacobian_mont_le(co.msm_best(sb, pb, n_sp)))
+    host[special] = (pb, sb)
+    keys = sizes + [special]
+    size_of = lambda k: abs(k)                        # noqa: E731
     checked = 0
     for r in range(a.rounds):
         cfg.set_window_size(rng.choice([0, 0, 0, 5, 9, 13, 15, 16, 17]))
         handles = []
         for b in range(4):                            # four batches in flight, 1..5 instances each, mixed sizes
-            pick = [rng.choice(sizes) for _ in range(rng.choice([1, 2, 3, 5, 8, 12]))]   # 8+: threaded host passes
-            h = cfg.submit_batch_device([pool[n][1] for n in pick], [pool[n][0] for n in pick], pick)
+            pick = [rng.choice(keys) for _ in range(rng.choice([1, 2, 3, 5, 8, 12]))]   # 8+: threaded host passes
+            h = cfg.submit_batch_device([pool[n][1] for n in pick], [pool[n][0] for n in pick], [size_of(n) for n in pick])
             handles.append((h, pick))
         for h, pick in rng.sample(handles, len(handles)):   # collected in random order
             outs = cfg.wait_batch(h)
@@ -44,14 +68,22 @@ def main():
                 assert o.decode_jacobian_mont_le(out) == pool[n][2], (r, n)
                 checked += 1
         if r % 3 == 0:                                # nothing in flight now: a LONE call (one stream, lone window policy),
-            n = rng.choice(sizes)                     # unsplit or forced into pipelined point ranges, device or host buffers
+            n = rng.choice(keys)                      # unsplit or forced into pipelined point ranges, device or host buffers
             parts = rng.choice(["1", "2", "3", "4", "8"])
             os.environ["MSM_AMD_SPLIT"] = parts
+            cfg.set_bases_cache(rng.choice([0, 0, 64 << 20]))   # the opt-in bases cache on and off (host calls)
             try:
-                if rng.random() < 0.5:
-                    out = cfg.msm_batch_device([pool[n][1]], [pool[n][0]], [n])[0]
-                else:
+                mode = rng.random()
+                if mode < 0.4:
+                    out = cfg.msm_batch_device([pool[n][1]], [pool[n][0]], [size_of(n)])[0]
+                elif mode < 0.7:
                     out = m.gpu_msm_h2c(host[n][1], host[n][0], cfg)
+                elif mode < 0.85:
+                    out = m.msm_best(host[n][1], host[n][0], cfg)
+                else:                                 # a host-slice batch of three
+                    out = cfg.msm_batch([host[n][1]] * 3, [host[n][0]] * 3, [size_of(n)] * 3)
+                    assert out[0] == out[1] == out[2]
+                    out = out[0]
             finally:
                 del os.environ["MSM_AMD_SPLIT"]
             assert o.decode_jacobian_mont_le(out) == pool[n][2], ("lone", r, n, parts)
