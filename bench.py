@@ -511,6 +511,17 @@ def drop_in_caller_figures(m, cfg, h_sc, h_pts, n, inst, expect):
         except Exception as e:   # noqa: BLE001
             return f"unavailable ({type(e).__name__})"
 
+    # the product's own CPU MSM (csrc/host_msm.hip: where the reference calls halo2curves -- gpu_profiler's cpu mode, the
+    # CPU half of gpu_with_cpu) on the same first instance: product code, NOT the cpu_baseline (that is the oracle's)
+    t0 = time.perf_counter()
+    cpu_out = m.host_msm(h_sc[0], h_pts[0], n, 0)
+    dt_cpu = time.perf_counter() - t0
+    if cpu_out != expect[0]:
+        raise SystemExit("PARITY FAILURE: the product's CPU MSM differs from the GPU result (byte comparison)")
+    res["product_cpu_msm"] = {"ms_per_msm": round(dt_cpu * 1e3, 2), "threads": m.lib().msm_amd_host_threads(),
+                              "byte_identical_to_gpu_result": True,
+                              "note": "msm_amd_host_msm, one cold call on instance 0 (no GPU involved)"}
+
     res["cli_system_runtime"] = {
         "e2e_host_slices_MSM_per_s": cli([]),
         "e2e_host_slices_bases_cache_MSM_per_s": cli(["--bases-cache", str((64 * n * inst * 2) >> 20)]),
