@@ -10,11 +10,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -89,6 +91,30 @@ struct BasesCacheEntry {
   uint32_t next_phase = 1;
 };
 
+// Upload of PAGEABLE host memory through the library's own page-locked ring: helper threads copy 4 MiB chunks into
+// pinned slots, each chunk goes on by DMA as soon as it is there.  The runtime's staged copy of pageable memory blocks
+// the calling thread either way; on the HIP 7.0 runtime (the one inside the PyTorch wheel) it also serialises with
+// the kernels of the other streams, this path does not (a page-locked source never did).
+struct Stager {
+  static constexpr size_t kChunk = (size_t)4 << 20;
+  static constexpr int kSlots = 4, kHelpers = 3;
+  void* slot[kSlots] = {};
+  hipEvent_t sent[kSlots] = {};
+  bool busy[kSlots] = {};
+  int next = 0;
+  bool ready = false;
+  // helper threads: copy parts 1 .. kHelpers of the current chunk (the caller copies part 0)
+  std::vector<std::thread> helpers;
+  std::mutex m;
+  std::condition_variable wake, finished;
+  const uint8_t* src = nullptr;
+  uint8_t* dst = nullptr;
+  size_t bytes = 0;
+  std::atomic<uint64_t> generation{0};
+  int pending = 0;
+  bool quit = false;
+};
+
 constexpr int kWorkspaces = 4;
 constexpr int kReduceStreams = 2;
 constexpr int kMaxBatches = 4;   // batches that may be in flight between submit and wait
@@ -161,6 +187,8 @@ struct msm_amd_ctx {
   // a submit it would stall the pipeline and, on a device that does not answer, block without bound.  They are
   // freed when the ctx has nothing in flight (reap_graveyard) or at msm_amd_destroy.
   std::vector<void*> graveyard;
+  Stager stager;
+  int staged_uploads = -1;   // -1 = decide by the runtime version (stage_pageable()), 0 / 1 = MSM_AMD_STAGED_UPLOAD
 };
 
 namespace {
@@ -961,6 +989,110 @@ bool pageable_uploads_overlap() {
   return ok;
 }
 
+void stager_worker(Stager* S, int part) {
+  uint64_t seen = 0;
+  for (;;) {
+    const uint8_t* src;
+    uint8_t* dst;
+    size_t bytes;
+    // chunks of one upload follow each other within ~100 us: spin that long before going to sleep on the condvar
+    for (int spin = 0; spin < 20000 && S->generation.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+    {
+      std::unique_lock<std::mutex> lk(S->m);
+      S->wake.wait(lk, [&] { return S->quit || S->generation.load() != seen; });
+      if (S->quit) return;
+      seen = S->generation.load();
+      src = S->src;
+      dst = S->dst;
+      bytes = S->bytes;
+    }
+    const size_t parts = Stager::kHelpers + 1, lo = bytes * part / parts, hi = bytes * (part + 1) / parts;
+    std::memcpy(dst + lo, src + lo, hi - lo);
+    {
+      std::lock_guard<std::mutex> lk(S->m);
+      if (--S->pending == 0) S->finished.notify_one();
+    }
+  }
+}
+
+int stager_prepare(msm_amd_ctx* ctx) {
+  Stager& S = ctx->stager;
+  if (S.ready) return MSM_AMD_OK;
+  for (int k = 0; k < Stager::kSlots; ++k) {
+    HIP_TRY(ctx, hipHostMalloc(&S.slot[k], Stager::kChunk, hipHostMallocDefault));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&S.sent[k], hipEventDisableTiming));
+  }
+  for (int h = 1; h <= Stager::kHelpers; ++h) S.helpers.emplace_back(stager_worker, &S, h);
+  S.ready = true;
+  return MSM_AMD_OK;
+}
+
+void stager_shutdown(msm_amd_ctx* ctx) {
+  Stager& S = ctx->stager;
+  if (!S.ready) return;
+  {
+    std::lock_guard<std::mutex> lk(S.m);
+    S.quit = true;
+  }
+  S.wake.notify_all();
+  for (std::thread& t : S.helpers) t.join();
+  S.helpers.clear();
+  for (int k = 0; k < Stager::kSlots; ++k) {
+    if (S.sent[k]) (void)hipEventDestroy(S.sent[k]);
+    if (S.slot[k]) (void)hipHostFree(S.slot[k]);
+    S.sent[k] = nullptr;
+    S.slot[k] = nullptr;
+  }
+  S.ready = false;
+}
+
+// Should a pageable upload of this size go through the ring?  By default where the runtime's own staged copy does not
+// overlap kernels (HIP < 7.2); MSM_AMD_STAGED_UPLOAD=0 / 1 overrides.
+bool stage_pageable(msm_amd_ctx* ctx, const void* src, size_t bytes) {
+  if (bytes < 2 * Stager::kChunk) return false;
+  if (ctx->staged_uploads < 0) {
+    const char* e = std::getenv("MSM_AMD_STAGED_UPLOAD");
+    ctx->staged_uploads = e ? (std::atoi(e) != 0) : (pageable_uploads_overlap() ? 0 : 1);
+  }
+  return ctx->staged_uploads == 1 && !host_pinned(src);
+}
+
+// hipMemcpyAsync(dst, src, bytes, H2D, stream) for a pageable src, through the ring.  Returns when the last chunk has
+// been handed to the DMA engine (the caller's buffer is no longer needed), not when it has arrived.
+int staged_upload(msm_amd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t stream) {
+  int rc;
+  if ((rc = stager_prepare(ctx))) return rc;
+  Stager& S = ctx->stager;
+  for (size_t off = 0; off < bytes; off += Stager::kChunk) {
+    const size_t len = std::min(Stager::kChunk, bytes - off);
+    const int k = S.next;
+    S.next = (S.next + 1) % Stager::kSlots;
+    if (S.busy[k]) {
+      if (wait_event(S.sent[k], ctx->wait_timeout_ms) != hipSuccess)
+        return fail(ctx, MSM_AMD_PIPELINE_ERROR, "timed out waiting for a staged upload chunk to leave its slot");
+      S.busy[k] = false;
+    }
+    {
+      std::lock_guard<std::mutex> lk(S.m);
+      S.src = (const uint8_t*)h_src + off;
+      S.dst = (uint8_t*)S.slot[k];
+      S.bytes = len;
+      S.pending = Stager::kHelpers;
+      ++S.generation;
+    }
+    S.wake.notify_all();
+    std::memcpy(S.slot[k], (const uint8_t*)h_src + off, len / (Stager::kHelpers + 1));   // part 0 on this thread
+    {
+      std::unique_lock<std::mutex> lk(S.m);
+      S.finished.wait(lk, [&] { return S.pending == 0; });
+    }
+    HIP_TRY(ctx, hipMemcpyAsync((uint8_t*)d_dst + off, S.slot[k], len, hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipEventRecord(S.sent[k], stream));
+    S.busy[k] = true;
+  }
+  return MSM_AMD_OK;
+}
+
 // A LONE call of many points runs as ONE PIPELINED BATCH of sub-instances over point ranges (the algebra of the
 // reference's GPU + CPU split, msm.rs:385-419: the MSM of a union of point ranges is the sum of the MSMs).  Alone, an
 // instance is a serial chain upload -> conversion / digits / sort -> accumulate -> reduction; as a batch, the front end
@@ -1245,11 +1377,21 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
     hipError_t e = hipSuccess;
     if (i >= 2)   // the staging set's previous reader
       e = hipStreamWaitEvent(ctx->copy_stream, ctx->batches[tickets[i - 2]].slots[0].ev[EV_DIGITS], 0);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(sbuf.p, scalars[i], n[i] * scalar_bytes(scalar_layout), hipMemcpyHostToDevice,
-                         ctx->copy_stream);
-    if (e == hipSuccess && !dev_points && !cached)
-      e = hipMemcpyAsync(pbuf.p, points[i], n[i] * pb, hipMemcpyHostToDevice, ctx->copy_stream);
+    if (e == hipSuccess) {
+      const size_t bytes = n[i] * scalar_bytes(scalar_layout);
+      if (stage_pageable(ctx, scalars[i], bytes)) {
+        if ((rc = staged_upload(ctx, sbuf.p, scalars[i], bytes, ctx->copy_stream))) return bail(rc);
+      } else {
+        e = hipMemcpyAsync(sbuf.p, scalars[i], bytes, hipMemcpyHostToDevice, ctx->copy_stream);
+      }
+    }
+    if (e == hipSuccess && !dev_points && !cached) {
+      if (stage_pageable(ctx, points[i], n[i] * pb)) {
+        if ((rc = staged_upload(ctx, pbuf.p, points[i], n[i] * pb, ctx->copy_stream))) return bail(rc);
+      } else {
+        e = hipMemcpyAsync(pbuf.p, points[i], n[i] * pb, hipMemcpyHostToDevice, ctx->copy_stream);
+      }
+    }
     if (e == hipSuccess) e = hipEventRecord(ctx->uploaded[i & 1], ctx->copy_stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(fs, ctx->uploaded[i & 1], 0);
     if (e != hipSuccess) return bail(fail(ctx, MSM_AMD_PIPELINE_ERROR, hipGetErrorString(e)));
@@ -1452,6 +1594,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   for (hipEvent_t& e : ctx->uploaded) kill_event(e);
   kill_event(ctx->upload_done);
   kill_event(ctx->after_sort_mark);
+  stager_shutdown(ctx);
   // 2. memory
   for (int k = 0; k < kWorkspaces; ++k) {
     Workspace& w = ctx->ws[k];
