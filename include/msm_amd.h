@@ -240,7 +240,8 @@ size_t msm_amd_shard_count(size_t n_inst, size_t n_ctx, size_t k);
 /* HIP device ordinal of a ctx. */
 int msm_amd_ctx_device(const msm_amd_ctx* ctx);
 /* Restrict the calling thread to the CPUs local to `device` (sysfs local_cpulist of its PCI function, intersected
- * with the thread's current mask).  0 = pinned, 1 = no NUMA information or nothing to intersect (not an error). */
+ * with the thread's current mask).  0 = pinned, 1 = no NUMA information or fewer than 8 CPUs to intersect (not an
+ * error; the mask is left alone). */
 int msm_amd_pin_thread_to_device(int device);
 
 /* RCCL all-gather of per-rank result blocks (one communicator per listed device, created in this process with

@@ -74,8 +74,8 @@ size_t msm_amd_shard_count(size_t n_inst, size_t n_ctx, size_t k) {
 }
 
 // Restrict the calling thread to the CPUs local to `device` (its PCI function's local_cpulist in sysfs), intersected
-// with the CPUs the thread may use now.  0 = pinned; 1 = nothing to do (no NUMA information, or the intersection is
-// empty -- a container that was granted CPUs of another node); never an error for the MSM itself.
+// with the CPUs the thread may use now.  0 = pinned; 1 = nothing done (no NUMA information, or the intersection has
+// fewer than 8 CPUs -- a container that was granted CPUs of another node); never an error for the MSM itself.
 int msm_amd_pin_thread_to_device(int device) {
   char bus[64] = {0};
   if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) {
@@ -91,7 +91,9 @@ int msm_amd_pin_thread_to_device(int device) {
   if (!parse_cpulist(line, &local)) return 1;
   if (sched_getaffinity(0, sizeof now, &now) != 0) return 1;
   CPU_AND(&both, &local, &now);
-  if (CPU_COUNT(&both) == 0) return 1;
+  // never squeeze a rank's threads (submission, Horner passes, its parity check) onto a handful of CPUs: a cpuset that
+  // barely touches the GPU's node is worse than no pinning
+  if (CPU_COUNT(&both) < 8 && CPU_COUNT(&both) < CPU_COUNT(&now)) return 1;
   return sched_setaffinity(0, sizeof both, &both) == 0 ? 0 : 1;
 }
 
