@@ -37,3 +37,12 @@ def test_bench_prints_one_contract_line():
         assert key in c, key
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["bit_exact_vs_gpu"] is True
     assert x["drop_in_caller"]["single_call_ms"]["resident_2^18"] < 5.0
+    # round 3: where the inputs live, build-derived instruction counts, the bases-cache figures beside the cache-off ones
+    assert "device-resident" in x["config"]["inputs"]
+    sec = r["secondary"]
+    assert 1500 <= sec["multiplier_instructions_per_mixed_addition"] <= 1600 and "isa_counts.json" in sec["counts_source"]
+    assert 0.3 < sec["frac"] < 0.9
+    d = x["drop_in_caller"]
+    assert d["e2e_host_slices_bases_cache_MSM_per_s"] > d["e2e_host_slices_MSM_per_s"] > 50
+    assert d["product_cpu_msm"]["byte_identical_to_gpu_result"] is True
+    assert isinstance(d["cli_system_runtime"]["e2e_host_slices_bases_cache_MSM_per_s"], float)
