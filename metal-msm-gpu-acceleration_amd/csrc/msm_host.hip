@@ -115,6 +115,29 @@ struct Stager {
   bool quit = false;
 };
 
+// The uploads of a host-slice batch run on a helper thread, one instance ahead of the thread that submits kernels: a
+// copy from pageable memory blocks whoever issues it (the runtime stages it, or staged_upload does), and on the
+// submitting thread that was 1.3 ms per 2^20-point instance during which nothing else got enqueued.
+struct UploadJob {
+  void* d_scalars = nullptr;
+  const void* h_scalars = nullptr;
+  size_t scalar_bytes = 0;
+  void* d_points = nullptr;
+  const void* h_points = nullptr;
+  size_t point_bytes = 0;          // 0: the points are resident (prepared bases, tables, a bases-cache hit)
+  hipEvent_t wait_for = nullptr;   // GPU-side: the previous reader of the staging set (nullptr: none)
+  hipEvent_t done = nullptr;       // recorded on the copy stream behind the copies
+};
+struct Uploader {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv, cv_idle;
+  UploadJob job;
+  bool has_job = false, busy = false, quit = false, started = false;
+  int status = 0;
+  std::string error;
+};
+
 constexpr int kWorkspaces = 4;
 constexpr int kReduceStreams = 2;
 constexpr int kMaxBatches = 4;   // batches that may be in flight between submit and wait
@@ -188,6 +211,7 @@ struct msm_amd_ctx {
   // freed when the ctx has nothing in flight (reap_graveyard) or at msm_amd_destroy.
   std::vector<void*> graveyard;
   Stager stager;
+  Uploader uploader;
   int staged_uploads = -1;   // -1 = decide by the runtime version (stage_pageable()), 0 / 1 = MSM_AMD_STAGED_UPLOAD
 };
 
@@ -196,8 +220,13 @@ namespace {
 std::mutex g_global_mu;
 msm_amd_ctx* g_global_ctx = nullptr;
 
+// A helper thread of the library (the uploader) reports through its own string: ctx->last_error belongs to the thread
+// that holds ctx->mu.
+thread_local std::string* tl_error_sink = nullptr;
+
 int fail(msm_amd_ctx* ctx, int status, const std::string& msg) {
-  if (ctx) ctx->last_error = msg;
+  if (tl_error_sink) *tl_error_sink = msg;
+  else if (ctx) ctx->last_error = msg;
   return status;
 }
 
@@ -1275,6 +1304,88 @@ int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size
   return wait_batch(ctx, ticket);
 }
 
+int upload_one(msm_amd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  if (stage_pageable(ctx, h_src, bytes)) return staged_upload(ctx, d_dst, h_src, bytes, ctx->copy_stream);
+  HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+  return MSM_AMD_OK;
+}
+
+void uploader_main(msm_amd_ctx* ctx) {
+  Uploader& U = ctx->uploader;
+  (void)hipSetDevice(ctx->device);
+  std::string my_error;
+  tl_error_sink = &my_error;
+  for (;;) {
+    UploadJob j;
+    {
+      std::unique_lock<std::mutex> lk(U.m);
+      U.cv.wait(lk, [&] { return U.quit || U.has_job; });
+      if (U.quit) return;
+      j = U.job;
+      U.has_job = false;
+    }
+    int rc = MSM_AMD_OK;
+    hipError_t e = hipSuccess;
+    if (j.wait_for) e = hipStreamWaitEvent(ctx->copy_stream, j.wait_for, 0);
+    if (e == hipSuccess) rc = upload_one(ctx, j.d_scalars, j.h_scalars, j.scalar_bytes);
+    if (e == hipSuccess && !rc && j.point_bytes) rc = upload_one(ctx, j.d_points, j.h_points, j.point_bytes);
+    if (e == hipSuccess && !rc) e = hipEventRecord(j.done, ctx->copy_stream);
+    {
+      std::lock_guard<std::mutex> lk(U.m);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rc = MSM_AMD_PIPELINE_ERROR;
+        U.error = std::string("upload: ") + hipGetErrorString(e);
+      } else if (rc) {
+        U.error = my_error;
+      }
+      U.status = rc;
+      U.busy = false;
+    }
+    U.cv_idle.notify_all();
+  }
+}
+
+void uploader_dispatch(msm_amd_ctx* ctx, const UploadJob& j) {
+  Uploader& U = ctx->uploader;
+  if (!U.started) {
+    U.th = std::thread(uploader_main, ctx);
+    U.started = true;
+  }
+  {
+    std::lock_guard<std::mutex> lk(U.m);
+    U.job = j;
+    U.has_job = true;
+    U.busy = true;
+  }
+  U.cv.notify_one();
+}
+
+int uploader_await(msm_amd_ctx* ctx) {   // the dispatched job has been enqueued completely (or has failed)
+  Uploader& U = ctx->uploader;
+  if (!U.started) return MSM_AMD_OK;
+  std::unique_lock<std::mutex> lk(U.m);
+  U.cv_idle.wait(lk, [&] { return !U.busy; });
+  const int rc = U.status;
+  U.status = MSM_AMD_OK;
+  if (rc) ctx->last_error = U.error;
+  return rc;
+}
+
+void uploader_shutdown(msm_amd_ctx* ctx) {
+  Uploader& U = ctx->uploader;
+  if (!U.started) return;
+  (void)uploader_await(ctx);
+  {
+    std::lock_guard<std::mutex> lk(U.m);
+    U.quit = true;
+  }
+  U.cv.notify_all();
+  U.th.join();
+  U.started = false;
+  U.quit = false;
+}
+
 // Host-buffer variant: stage inputs into device scratch, then run the device path per instance.
 int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t n_inst, const void* const* scalars,
                    const void* const* points, const size_t* n, void* out) {
@@ -1359,50 +1470,54 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
   const bool lone = lone_call(ctx, n_inst);
   hipStream_t fs = front_stream_of(ctx, lone);
   const bool use_cache = ctx->bases_cache_budget != 0 && !dev_points;
+  // bases cache (opt-in): a hit replaces the 64..96 B per point upload and the conversion by the resident converted
+  // copy; a miss uploads as usual and converts straight into the new entry (the reference re-uploads and re-converts
+  // the bases on every call, msm.rs:152-153; its callers pass the same SRS slice again and again,
+  // benches/msm_benchmark.rs:116-121)
+  std::vector<const void*> cached(n_inst, nullptr);
+  std::vector<AffPacked*> fill(n_inst, nullptr);
+  // upload of instance j on the helper thread (uploader_main), decided and dispatched by this one
+  auto dispatch = [&](size_t j) {
+    if (use_cache) {
+      if (BasesCacheEntry* e = bases_cache_lookup(ctx, points[j], n[j], point_layout)) cached[j] = e->d_prepared;
+      else if (BasesCacheEntry* f = bases_cache_insert(ctx, points[j], n[j], point_layout)) fill[j] = (AffPacked*)f->d_prepared;
+    }
+    UploadJob job;
+    job.d_scalars = ((j & 1) ? ctx->scratch_b2 : ctx->scratch_b).p;
+    job.h_scalars = scalars[j];
+    job.scalar_bytes = n[j] * scalar_bytes(scalar_layout);
+    if (!dev_points && !cached[j]) {
+      job.d_points = ((j & 1) ? ctx->scratch_c2 : ctx->scratch_c).p;
+      job.h_points = points[j];
+      job.point_bytes = n[j] * pb;
+    }
+    // the staging set's previous reader is instance j - 2: its front end has read the set once its digits are done
+    if (j >= 2) job.wait_for = ctx->batches[tickets[j - 2]].slots[0].ev[EV_DIGITS];
+    job.done = ctx->uploaded[j & 1];
+    uploader_dispatch(ctx, job);
+  };
+  auto bail_upload = [&](int rc) {   // the helper may still be reading the caller's buffers
+    (void)uploader_await(ctx);
+    return bail(rc);
+  };
+  dispatch(0);
   for (size_t i = 0; i < n_inst; ++i) {
     int rc;
-    if (i >= kInflight && (rc = collect(i - kInflight))) return bail(rc);
-    DeviceBuf& sbuf = (i & 1) ? ctx->scratch_b2 : ctx->scratch_b;
-    DeviceBuf& pbuf = (i & 1) ? ctx->scratch_c2 : ctx->scratch_c;
-    // bases cache (opt-in): a hit replaces the 64..96 B per point upload and the conversion by the resident converted
-    // copy; a miss uploads as usual and converts straight into the new entry (the reference re-uploads and re-converts
-    // the bases on every call, msm.rs:152-153; its callers pass the same SRS slice again and again,
-    // benches/msm_benchmark.rs:116-121)
-    const void* cached = nullptr;
-    AffPacked* fill = nullptr;
-    if (use_cache) {
-      if (BasesCacheEntry* e = bases_cache_lookup(ctx, points[i], n[i], point_layout)) cached = e->d_prepared;
-      else if (BasesCacheEntry* f = bases_cache_insert(ctx, points[i], n[i], point_layout)) fill = (AffPacked*)f->d_prepared;
-    }
-    hipError_t e = hipSuccess;
-    if (i >= 2)   // the staging set's previous reader
-      e = hipStreamWaitEvent(ctx->copy_stream, ctx->batches[tickets[i - 2]].slots[0].ev[EV_DIGITS], 0);
-    if (e == hipSuccess) {
-      const size_t bytes = n[i] * scalar_bytes(scalar_layout);
-      if (stage_pageable(ctx, scalars[i], bytes)) {
-        if ((rc = staged_upload(ctx, sbuf.p, scalars[i], bytes, ctx->copy_stream))) return bail(rc);
-      } else {
-        e = hipMemcpyAsync(sbuf.p, scalars[i], bytes, hipMemcpyHostToDevice, ctx->copy_stream);
-      }
-    }
-    if (e == hipSuccess && !dev_points && !cached) {
-      if (stage_pageable(ctx, points[i], n[i] * pb)) {
-        if ((rc = staged_upload(ctx, pbuf.p, points[i], n[i] * pb, ctx->copy_stream))) return bail(rc);
-      } else {
-        e = hipMemcpyAsync(pbuf.p, points[i], n[i] * pb, hipMemcpyHostToDevice, ctx->copy_stream);
-      }
-    }
-    if (e == hipSuccess) e = hipEventRecord(ctx->uploaded[i & 1], ctx->copy_stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(fs, ctx->uploaded[i & 1], 0);
-    if (e != hipSuccess) return bail(fail(ctx, MSM_AMD_PIPELINE_ERROR, hipGetErrorString(e)));
-    const void* ds = sbuf.p;
-    const void* dp = dev_points ? points[i] : (cached ? cached : pbuf.p);
+    if (i >= kInflight && (rc = collect(i - kInflight))) return bail_upload(rc);
+    if ((rc = uploader_await(ctx))) return bail(rc);   // upload i is enqueued, uploaded[i & 1] recorded
+    // upload i + 1 goes on while this thread enqueues the kernels of instance i (its staging set was last read by
+    // instance i - 1, submitted in the previous iteration)
+    if (i + 1 < n_inst) dispatch(i + 1);
+    const hipError_t e = hipStreamWaitEvent(fs, ctx->uploaded[i & 1], 0);
+    if (e != hipSuccess) return bail_upload(fail(ctx, MSM_AMD_PIPELINE_ERROR, hipGetErrorString(e)));
+    const void* ds = ((i & 1) ? ctx->scratch_b2 : ctx->scratch_b).p;
+    const void* dp = dev_points ? points[i] : (cached[i] ? cached[i] : ((i & 1) ? ctx->scratch_c2 : ctx->scratch_c).p);
     int ticket = -1;
-    ctx->convert_into = fill;
-    rc = submit_batch_device(ctx, scalar_layout, cached ? (int)MSM_AMD_POINT_PREPARED : point_layout, 1, &ds, &dp, &n[i],
+    ctx->convert_into = fill[i];
+    rc = submit_batch_device(ctx, scalar_layout, cached[i] ? (int)MSM_AMD_POINT_PREPARED : point_layout, 1, &ds, &dp, &n[i],
                              (uint8_t*)out + i * 96, &ticket, lone ? 1 : 0);
     ctx->convert_into = nullptr;
-    if (rc) return bail(rc);
+    if (rc) return bail_upload(rc);
     tickets[i] = ticket;
   }
   for (size_t i = n_inst > kInflight ? n_inst - kInflight : 0; i < n_inst; ++i) {
@@ -1594,6 +1709,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   for (hipEvent_t& e : ctx->uploaded) kill_event(e);
   kill_event(ctx->upload_done);
   kill_event(ctx->after_sort_mark);
+  uploader_shutdown(ctx);
   stager_shutdown(ctx);
   // 2. memory
   for (int k = 0; k < kWorkspaces; ++k) {
