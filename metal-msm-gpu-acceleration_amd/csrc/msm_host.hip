@@ -1304,8 +1304,8 @@ int run_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size
   return wait_batch(ctx, ticket);
 }
 
-int upload_one(msm_amd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
-  if (stage_pageable(ctx, h_src, bytes)) return staged_upload(ctx, d_dst, h_src, bytes, ctx->copy_stream);
+int upload_one(msm_amd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, bool ring = true) {
+  if (ring && stage_pageable(ctx, h_src, bytes)) return staged_upload(ctx, d_dst, h_src, bytes, ctx->copy_stream);
   HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
   return MSM_AMD_OK;
 }
@@ -1477,7 +1477,7 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
   std::vector<const void*> cached(n_inst, nullptr);
   std::vector<AffPacked*> fill(n_inst, nullptr);
   // upload of instance j on the helper thread (uploader_main), decided and dispatched by this one
-  auto dispatch = [&](size_t j) {
+  auto dispatch = [&](size_t j) -> int {
     if (use_cache) {
       if (BasesCacheEntry* e = bases_cache_lookup(ctx, points[j], n[j], point_layout)) cached[j] = e->d_prepared;
       else if (BasesCacheEntry* f = bases_cache_insert(ctx, points[j], n[j], point_layout)) fill[j] = (AffPacked*)f->d_prepared;
@@ -1494,20 +1494,32 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
     // the staging set's previous reader is instance j - 2: its front end has read the set once its digits are done
     if (j >= 2) job.wait_for = ctx->batches[tickets[j - 2]].slots[0].ev[EV_DIGITS];
     job.done = ctx->uploaded[j & 1];
-    uploader_dispatch(ctx, job);
+    if (n_inst > 1) {
+      uploader_dispatch(ctx, job);
+      return (int)MSM_AMD_OK;
+    }
+    // ONE instance: nothing to overlap the upload with -- the plain copy on this thread is the shortest path (the
+    // helper thread's hand-offs and the ring cost a lone 2^18 call 0.2 ms, measured)
+    int rc = upload_one(ctx, job.d_scalars, job.h_scalars, job.scalar_bytes, false);
+    if (!rc && job.point_bytes) rc = upload_one(ctx, job.d_points, job.h_points, job.point_bytes, false);
+    if (!rc && hipEventRecord(job.done, ctx->copy_stream) != hipSuccess) {
+      (void)hipGetLastError();
+      rc = fail(ctx, MSM_AMD_PIPELINE_ERROR, "hipEventRecord(uploaded)");
+    }
+    return rc;
   };
   auto bail_upload = [&](int rc) {   // the helper may still be reading the caller's buffers
     (void)uploader_await(ctx);
     return bail(rc);
   };
-  dispatch(0);
+  if (int rc0 = dispatch(0)) return bail(rc0);
   for (size_t i = 0; i < n_inst; ++i) {
     int rc;
     if (i >= kInflight && (rc = collect(i - kInflight))) return bail_upload(rc);
-    if ((rc = uploader_await(ctx))) return bail(rc);   // upload i is enqueued, uploaded[i & 1] recorded
+    if (n_inst > 1 && (rc = uploader_await(ctx))) return bail(rc);   // upload i is enqueued, uploaded[i & 1] recorded
     // upload i + 1 goes on while this thread enqueues the kernels of instance i (its staging set was last read by
     // instance i - 1, submitted in the previous iteration)
-    if (i + 1 < n_inst) dispatch(i + 1);
+    if (i + 1 < n_inst) (void)dispatch(i + 1);
     const hipError_t e = hipStreamWaitEvent(fs, ctx->uploaded[i & 1], 0);
     if (e != hipSuccess) return bail_upload(fail(ctx, MSM_AMD_PIPELINE_ERROR, hipGetErrorString(e)));
     const void* ds = ((i & 1) ? ctx->scratch_b2 : ctx->scratch_b).p;
