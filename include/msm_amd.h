@@ -306,6 +306,10 @@ int msm_amd_synchronize(msm_amd_ctx* ctx);
 int msm_amd_generate_instance(msm_amd_ctx* ctx, uint64_t seed, size_t n, int scalars_mont, void* d_points,
                               void* d_scalars);
 
+/* Unit-test hook of the CPU MSM's AVX-512 IFMA arithmetic (csrc/host_ifma.cpp): count canonical field elements of
+ * 4 x u64 LE each.  op 0: a b / 2^260 mod p; 1: a - b mod p; 2: -a mod p (a != 0); 3: a 2^4 mod p (R -> Q domain);
+ * 4: a / 2^4 mod p (Q -> R).  MSM_AMD_FUNCTION_ERROR on a host without IFMA. */
+int msm_amd_test_op_ifma(int op, const void* a, const void* b, void* out, size_t count);
 /* The same instance generated on the host (identical bytes; no ctx, no GPU): inputs of `gpu_profiler ... cpu`. */
 int msm_amd_generate_instance_host(uint64_t seed, size_t n, int scalars_mont, void* points, void* scalars, int threads);
 

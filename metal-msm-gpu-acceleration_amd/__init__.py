@@ -53,7 +53,7 @@ EXPORTS = [
     "msm_amd_test_release", "msm_amd_msm_batch_multi", "msm_amd_msm_batch_multi_device", "msm_amd_shard_owner",
     "msm_amd_shard_count", "msm_amd_ctx_device", "msm_amd_pin_thread_to_device", "msm_amd_gather_init",
     "msm_amd_gather_size", "msm_amd_gather_all", "msm_amd_gather_last_error", "msm_amd_gather_destroy",
-    "msm_amd_host_msm", "msm_amd_tuned_split", "msm_amd_host_threads", "msm_amd_generate_instance_host",
+    "msm_amd_host_msm", "msm_amd_tuned_split", "msm_amd_host_threads", "msm_amd_generate_instance_host", "msm_amd_test_op_ifma",
 ]
 
 
@@ -186,6 +186,7 @@ def _lib():
         L.msm_amd_gather_destroy.restype = None
         L.msm_amd_host_msm.argtypes = [c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]
         L.msm_amd_generate_instance_host.argtypes = [c_uint64, c_size_t, c_int, c_void_p, c_void_p, c_int]
+        L.msm_amd_test_op_ifma.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_size_t]
         L.msm_amd_tuned_split.argtypes = [c_size_t]
         L.msm_amd_tuned_split.restype = c_size_t
         _LIB = L

@@ -244,6 +244,35 @@ MSM_IFMA inline V5 neg_canon(const V5& a, const Consts& K) {
   return r;
 }
 
+// Single operations for the unit tests (tests/test_host_ifma.py): a, b, out = count field elements of 4 x u64,
+// canonical in and out.  op 0: a * b / 2^260 mod p   1: a - b mod p   2: -a mod p (a != 0)
+MSM_IFMA void test_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count) {
+  const Consts& K = consts();
+  alignas(64) uint64_t ba[4][8], bb[4][8];
+  for (size_t at = 0; at < count; at += 8) {
+    const size_t m = count - at < 8 ? count - at : 8;
+    for (int j = 0; j < 4; ++j)
+      for (size_t k = 0; k < 8; ++k) {
+        ba[j][k] = k < m ? a[(at + k) * 4 + j] : (j == 0 ? 1 : 0);
+        bb[j][k] = k < m ? b[(at + k) * 4 + j] : (j == 0 ? 1 : 0);
+      }
+    __m512i wa[4], wb[4];
+    for (int j = 0; j < 4; ++j) {
+      wa[j] = _mm512_load_si512(ba[j]);
+      wb[j] = _mm512_load_si512(bb[j]);
+    }
+    const V5 x = from_words(wa), y = from_words(wb);
+    V5 r;
+    if (op == 0) r = canon(mont(x, y, K), K);
+    else if (op == 1) r = canon(sub2p(x, y, K), K);
+    else r = neg_canon(x, K);
+    to_words(r, wa);
+    for (int j = 0; j < 4; ++j) _mm512_store_si512(ba[j], wa[j]);
+    for (int j = 0; j < 4; ++j)
+      for (size_t k = 0; k < m; ++k) out[(at + k) * 4 + j] = ba[j][k];
+  }
+}
+
 // Forward pass of one batch: element k adds point number (pt_idx[k] & 0x7FFFFFFF) of `pts` (8 u64 per point: x, y),
 // negated when bit 31 of pt_idx[k] is set, to bucket buckets[8 * bucket_idx[k] ..].
 // Computes d = x2 - x1 and the running products of eight interleaved chains (lane = k mod 8); returns the eight chain

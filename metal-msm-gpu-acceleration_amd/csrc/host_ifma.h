@@ -17,7 +17,9 @@ struct Scratch {
   int rows = 0;
 };
 
-bool available();   // CPUID: AVX-512 F / IFMA / DQ / VL / BW
+bool available();
+// unit-test hook: count field elements of 4 x u64, canonical; op 0: a b / 2^260, 1: a - b, 2: -a (all mod p)
+void test_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count);   // CPUID: AVX-512 F / IFMA / DQ / VL / BW
 void convert(const uint64_t* in, uint64_t* out, size_t n, int dir);   // dir 0: R (2^256) -> Q (2^260) domain, 1: back
 // pt_idx[k]: index of the point in `pts` (8 u64 per point), bit 31 set = add the negative
 void forward(const uint64_t* buckets, const uint32_t* bucket_idx, const uint64_t* pts, const uint32_t* pt_idx, int count,

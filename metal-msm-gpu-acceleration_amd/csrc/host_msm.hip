@@ -615,6 +615,18 @@ int msm_amd_host_msm(int scalar_layout, int point_layout, const void* scalars, c
   return MSM_AMD_OK;
 }
 
+// Unit-test hook of the AVX-512 IFMA arithmetic (host_ifma.cpp).  Returns MSM_AMD_FUNCTION_ERROR on a host without
+// IFMA (the CPU MSM then takes its scalar path and there is nothing to test).  op 0: a b / 2^260 mod p, 1: a - b mod p,
+// 2: -a mod p (a != 0), 3: R-domain -> Q-domain (a 2^4), 4: back; operands canonical 4 x u64 little-endian.
+int msm_amd_test_op_ifma(int op, const void* a, const void* b, void* out, size_t count) {
+  using namespace msm_amd;
+  if (!a || !b || !out || count == 0 || op < 0 || op > 4) return MSM_AMD_INPUT_ERROR;
+  if (!ifma::available()) return MSM_AMD_FUNCTION_ERROR;
+  if (op <= 2) ifma::test_op(op, (const uint64_t*)a, (const uint64_t*)b, (uint64_t*)out, count);
+  else ifma::convert((const uint64_t*)a, (uint64_t*)out, count, op == 3 ? 0 : 1);
+  return MSM_AMD_OK;
+}
+
 // The deterministic synthetic instance of msm_amd_generate_instance, generated on the host (same generator code,
 // identical bytes): `gpu_profiler ... cpu` needs no GPU at all, like the reference's `cpu` mode.
 int msm_amd_generate_instance_host(uint64_t seed, size_t n, int scalars_mont, void* points, void* scalars, int threads) {
