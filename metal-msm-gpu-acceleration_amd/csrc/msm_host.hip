@@ -97,13 +97,14 @@ struct BasesCacheEntry {
 // the kernels of the other streams, this path does not (a page-locked source never did).
 struct Stager {
   static constexpr size_t kChunk = (size_t)4 << 20;
-  static constexpr int kSlots = 4, kHelpers = 3;
+  static constexpr int kSlots = 4, kMaxHelpers = 7;
+  int n_helpers = 3;   // MSM_AMD_STAGE_HELPERS = 1 .. 7 overrides (measured: profiles/r03_staged_upload_helpers.txt)
   void* slot[kSlots] = {};
   hipEvent_t sent[kSlots] = {};
   bool busy[kSlots] = {};
   int next = 0;
   bool ready = false;
-  // helper threads: copy parts 1 .. kHelpers of the current chunk (the caller copies part 0)
+  // helper threads: copy parts 1 .. n_helpers of the current chunk (the caller copies part 0)
   std::vector<std::thread> helpers;
   std::mutex m;
   std::condition_variable wake, finished;
@@ -1035,7 +1036,7 @@ void stager_worker(Stager* S, int part) {
       dst = S->dst;
       bytes = S->bytes;
     }
-    const size_t parts = Stager::kHelpers + 1, lo = bytes * part / parts, hi = bytes * (part + 1) / parts;
+    const size_t parts = (size_t)S->n_helpers + 1, lo = bytes * part / parts, hi = bytes * (part + 1) / parts;
     std::memcpy(dst + lo, src + lo, hi - lo);
     {
       std::lock_guard<std::mutex> lk(S->m);
@@ -1051,7 +1052,8 @@ int stager_prepare(msm_amd_ctx* ctx) {
     HIP_TRY(ctx, hipHostMalloc(&S.slot[k], Stager::kChunk, hipHostMallocDefault));
     HIP_TRY(ctx, hipEventCreateWithFlags(&S.sent[k], hipEventDisableTiming));
   }
-  for (int h = 1; h <= Stager::kHelpers; ++h) S.helpers.emplace_back(stager_worker, &S, h);
+  if (const char* e = std::getenv("MSM_AMD_STAGE_HELPERS")) S.n_helpers = std::max(1, std::min(Stager::kMaxHelpers, std::atoi(e)));
+  for (int h = 1; h <= S.n_helpers; ++h) S.helpers.emplace_back(stager_worker, &S, h);
   S.ready = true;
   return MSM_AMD_OK;
 }
@@ -1106,11 +1108,11 @@ int staged_upload(msm_amd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes
       S.src = (const uint8_t*)h_src + off;
       S.dst = (uint8_t*)S.slot[k];
       S.bytes = len;
-      S.pending = Stager::kHelpers;
+      S.pending = S.n_helpers;
       ++S.generation;
     }
     S.wake.notify_all();
-    std::memcpy(S.slot[k], (const uint8_t*)h_src + off, len / (Stager::kHelpers + 1));   // part 0 on this thread
+    std::memcpy(S.slot[k], (const uint8_t*)h_src + off, len / ((size_t)S.n_helpers + 1));   // part 0 on this thread
     {
       std::unique_lock<std::mutex> lk(S.m);
       S.finished.wait(lk, [&] { return S.pending == 0; });
