@@ -171,6 +171,31 @@ def test_log24_ark_projective_dlog_identity(cfg, msm_pkg):
             cfg.free(d_proj)
 
 
+def test_log26_resident_dlog_identity(cfg, msm_pkg):
+    """Four times configs[4]'s size: 2^26 points (4 GiB of bases, 2 GiB of scalars, device-resident), the call runs as
+    8 pipelined point ranges of 2^23.  Checked by the dlog identity; 2^28 points (the largest power of two below the
+    API's 2^31 - 1 bound whose buffers the tool builds, 349 ms) are exercised by tools/dbg/big.py, profiles/r03_big_sizes.txt."""
+    n = 1 << 26
+    rng = random.Random(2026)
+    a0, d = rng.randrange(o.R_ORDER), rng.randrange(o.R_ORDER)
+    dp, ds = cfg.generate_instance(o.SEED_BASE + 260, n, True)
+    cfg.free(dp)
+    dpts = None
+    try:
+        sb = cfg.to_host(ds, 32 * n)
+        pb, expect = co.dlog_instance(a0, d, sb, n)
+        del sb
+        dpts = cfg.alloc(64 * n)
+        cfg.to_device(dpts, pb)
+        del pb
+        out = cfg.msm_batch_device([ds], [dpts], [n])[0]
+        assert o.decode_jacobian_mont_le(out) == o.decode_jacobian_mont_le(expect)
+    finally:
+        cfg.free(ds)
+        if dpts is not None:
+            cfg.free(dpts)
+
+
 def test_headline_shape_two_batches_in_flight_dlog(cfg, msm_pkg):
     """The bench's shape: 2 batches x 5 instances of 2^20 points in flight through submit_batch_device / wait_batch
     (4 workspaces, 4 streams, both reduce streams busy).  Bases are dlog-structured, P_i = (a0 + i d) G, so every one
