@@ -234,6 +234,16 @@ int msm_amd_msm_batch_multi(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_l
 int msm_amd_msm_batch_multi_device(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout,
                                    size_t n_inst, const void* const* d_scalars, const void* const* d_points,
                                    const size_t* n, void* out_host);
+/* ONE instance of n points over several ctxs, split by point range ("single huge instance"):
+ * ctx g uploads and runs the MSM of points [begin_g, end_g) (msm_amd_shard_range), the partial results are added with
+ * msm_amd_sum_points -- the algebra of the reference's GPU + CPU split, src/metal/msm.rs:385-419.  Host buffers in a
+ * host layout (not MSM_AMD_POINT_PREPARED / _TABLES, which belong to one ctx); out96 as msm_amd_msm. */
+int msm_amd_msm_range_multi(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout,
+                            const void* scalars, const void* points, size_t n, void* out96);
+void msm_amd_shard_range(size_t n, size_t n_ctx, size_t k, size_t* begin, size_t* end);
+/* Bytes per element of a layout (0 = unknown layout). */
+size_t msm_amd_scalar_bytes(int scalar_layout);
+size_t msm_amd_point_bytes(int point_layout);
 /* The sharding arithmetic: owner of instance j, and how many instances ctx k of n_ctx gets. */
 size_t msm_amd_shard_owner(size_t instance, size_t n_ctx);
 size_t msm_amd_shard_count(size_t n_inst, size_t n_ctx, size_t k);

@@ -50,7 +50,8 @@ EXPORTS = [
     "msm_amd_msm_prepared", "msm_amd_sum_points", "msm_amd_tables_build", "msm_amd_tables_build_device",
     "msm_amd_tables_info", "msm_amd_tables_free", "msm_amd_msm_tables",
     "msm_amd_set_wait_timeout_ms", "msm_amd_set_bases_cache", "msm_amd_bases_cache_stats", "msm_amd_test_hold",
-    "msm_amd_test_release", "msm_amd_msm_batch_multi", "msm_amd_msm_batch_multi_device", "msm_amd_shard_owner",
+    "msm_amd_test_release", "msm_amd_msm_batch_multi", "msm_amd_msm_batch_multi_device", "msm_amd_msm_range_multi", "msm_amd_shard_range",
+    "msm_amd_scalar_bytes", "msm_amd_point_bytes", "msm_amd_shard_owner",
     "msm_amd_shard_count", "msm_amd_ctx_device", "msm_amd_pin_thread_to_device", "msm_amd_gather_init",
     "msm_amd_gather_size", "msm_amd_gather_all", "msm_amd_gather_last_error", "msm_amd_gather_destroy",
     "msm_amd_host_msm", "msm_amd_tuned_split", "msm_amd_host_threads", "msm_amd_generate_instance_host", "msm_amd_test_op_ifma",
@@ -171,6 +172,14 @@ def _lib():
         L.msm_amd_msm_batch_multi.argtypes = [POINTER(c_void_p), c_size_t, c_int, c_int, c_size_t, POINTER(c_void_p),
                                               POINTER(c_void_p), POINTER(c_size_t), c_void_p]
         L.msm_amd_msm_batch_multi_device.argtypes = L.msm_amd_msm_batch_multi.argtypes
+        L.msm_amd_msm_range_multi.argtypes = [POINTER(c_void_p), c_size_t, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                              c_void_p]
+        L.msm_amd_shard_range.argtypes = [c_size_t, c_size_t, c_size_t, POINTER(c_size_t), POINTER(c_size_t)]
+        L.msm_amd_shard_range.restype = None
+        L.msm_amd_scalar_bytes.argtypes = [c_int]
+        L.msm_amd_scalar_bytes.restype = c_size_t
+        L.msm_amd_point_bytes.argtypes = [c_int]
+        L.msm_amd_point_bytes.restype = c_size_t
         L.msm_amd_shard_owner.argtypes = [c_size_t, c_size_t]
         L.msm_amd_shard_owner.restype = c_size_t
         L.msm_amd_shard_count.argtypes = [c_size_t, c_size_t, c_size_t]
@@ -454,6 +463,25 @@ def msm_batch_multi(configs, scalars_list, points_list, ns, scalar_layout=SCALAR
         detail = "; ".join(_lib().msm_amd_last_error(c.h).decode() for c in configs)
         raise MsmError(st, detail)
     return [out.raw[96 * i:96 * i + 96] for i in range(k)]
+
+
+def msm_range_multi(configs, scalars: bytes, points: bytes, n: int, scalar_layout=SCALAR_MONT_LE,
+                    point_layout=POINT_H2C_AFFINE) -> bytes:
+    """ONE instance split by point range over several configs (msm_amd_msm_range_multi): config g uploads and runs the
+    points of msm_amd_shard_range(n, G, g), the partial results are added."""
+    g = len(configs)
+    cc = (c_void_p * g)(*[c.h for c in configs])
+    out = ctypes.create_string_buffer(96)
+    st = _lib().msm_amd_msm_range_multi(cc, g, scalar_layout, point_layout, scalars, points, n, out)
+    if st != OK:
+        raise MsmError(st, "; ".join(_lib().msm_amd_last_error(c.h).decode() for c in configs))
+    return out.raw
+
+
+def shard_range(n: int, n_ctx: int, k: int):
+    b, e = c_size_t(0), c_size_t(0)
+    _lib().msm_amd_shard_range(n, n_ctx, k, ctypes.byref(b), ctypes.byref(e))
+    return b.value, e.value
 
 
 def shard_owner(instance: int, n_ctx: int) -> int:

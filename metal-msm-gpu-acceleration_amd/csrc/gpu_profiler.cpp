@@ -10,6 +10,8 @@
 //                               afterwards the per-GPU result blocks are all-gathered over RCCL (xGMI) and compared
 //                [--devices a,b,..]  the device ordinals to use instead of 0..N-1 (a device may repeat: contexts then
 //                               share it and the RCCL gather, which refuses duplicates, is skipped)
+//                [--range-split]  with --gpus / --devices in gpu mode: every instance is split by POINT RANGE over all
+//                               contexts instead (msm_amd_msm_range_multi: the "single huge instance" sharding)
 //                [--no-rccl]    skip the RCCL gather (results are gathered through host memory anyway)
 //                [--threads T]  host threads of the cpu / gpu_cpu modes (default: every CPU the process may use)
 //                [--reference-split]  gpu_cpu: the reference's split policy instead of the one measured on MI355X
@@ -74,7 +76,7 @@ int main(int argc, char** argv) {
   int device = -1, window = 0, gpus = 1, threads = 0;
   unsigned warmup = 0;
   size_t cache_mb = 0;
-  bool json = false, no_rccl = false, reference_split = false;
+  bool json = false, no_rccl = false, reference_split = false, range_split = false;
   bool ark = false;   // --layout ark: ark_bn254 G1Projective points (96 B, z = one), config 5 of BASELINE.json
   bool use_vecs = false;   // --vec-dir DIR | --vec-cache: inputs come from / go to the reference's instance file
   std::string vec_dir;
@@ -99,6 +101,7 @@ int main(int argc, char** argv) {
       }
     }
     else if (a == "--no-rccl") no_rccl = true;
+    else if (a == "--range-split") range_split = true;
     else if (a == "--threads" && i + 1 < argc) threads = std::atoi(argv[++i]);
     else if (a == "--reference-split") reference_split = true;
     else if (a == "--bases-cache" && i + 1 < argc) cache_mb = (size_t)std::strtoull(argv[++i], nullptr, 10);
@@ -128,6 +131,8 @@ int main(int argc, char** argv) {
   const bool multi = gpus > 1 || !devices.empty();
   if (multi && mode != "gpu" && mode != "gpu_resident") return fail("--gpus / --devices shard the gpu and gpu_resident modes");
   if (multi && (ark || use_vecs)) return fail("--gpus / --devices take the h2c layout and generated instances");
+  if (range_split && (!multi || mode != "gpu")) return fail("--range-split needs --gpus / --devices and the gpu mode (host buffers)");
+  if (range_split) no_rccl = true;   // the partial results are added inside msm_amd_msm_range_multi; nothing to gather
   if (threads <= 0) threads = msm_amd_host_threads();
 
   const size_t n = (size_t)1 << log_size;
@@ -296,7 +301,16 @@ int main(int argc, char** argv) {
   auto t0 = std::chrono::steady_clock::now();
   for (unsigned r = 0; r < retries + warmup; ++r) {
     if (r == warmup) t0 = std::chrono::steady_clock::now();
-    if (multi) {   // the sharded instance loop
+    if (multi && range_split) {   // every instance over all contexts, by point range
+      for (unsigned j = 0; j < num_instances && !st; ++j)
+        st = msm_amd_msm_range_multi(g_ctxs.data(), G, sc_layout, pt_layout, h_sc[j].data(), h_pts[j].data(), n,
+                                     out.data() + (size_t)j * 96);
+      if (st) {
+        for (msm_amd_ctx* c : g_ctxs)
+          if (*msm_amd_last_error(c)) std::fprintf(stderr, "[ERROR] device %d: %s\n", msm_amd_ctx_device(c), msm_amd_last_error(c));
+        die(nullptr, st, "msm_range_multi");
+      }
+    } else if (multi) {   // the sharded instance loop
       for (unsigned j = 0; j < num_instances; ++j) {
         sp[j] = host_inputs ? (const void*)h_sc[j].data() : d_sc[j];
         pp[j] = host_inputs ? (const void*)h_pts[j].data() : d_pts[j];

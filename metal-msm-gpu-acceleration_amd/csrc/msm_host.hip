@@ -2483,6 +2483,12 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   return MSM_AMD_OK;
 }
 
+size_t msm_amd_scalar_bytes(int scalar_layout) {
+  return (scalar_layout == MSM_AMD_SCALAR_MONT_LE || scalar_layout == MSM_AMD_SCALAR_CANON_LE ||
+          scalar_layout == MSM_AMD_SCALAR_CANON_BE32) ? 32 : 0;
+}
+size_t msm_amd_point_bytes(int point_layout) { return point_bytes(point_layout); }
+
 int msm_amd_sum_points(const void* points96, size_t count, void* out96) {
   if ((!points96 && count) || !out96) return MSM_AMD_INPUT_ERROR;
   h64::Jac acc = h64::identity();

@@ -152,6 +152,43 @@ int msm_amd_msm_batch_multi_device(msm_amd_ctx* const* ctxs, size_t n_ctx, int s
   return batch_multi(ctxs, n_ctx, scalar_layout, point_layout, n_inst, d_scalars, d_points, n, out_host, 1);
 }
 
+// ONE instance over several ctxs, split by point range: ctx g runs the MSM of points [begin_g, end_g) over all
+// windows and the partial results are added -- the MSM of a union of point ranges is the sum of the MSMs, the algebra
+// of the reference's GPU + CPU split (src/metal/msm.rs:385-419; SURVEY.md section 8e, "single huge instance").  Host
+// buffers only: every ctx uploads its own range.  Ranges are the n / G split with the remainder on the first ranges.
+void msm_amd_shard_range(size_t n, size_t n_ctx, size_t k, size_t* begin, size_t* end) {
+  size_t b = 0, e = 0;
+  if (n_ctx && k < n_ctx) {
+    const size_t base = n / n_ctx, extra = n % n_ctx;
+    b = k * base + std::min(k, extra);
+    e = b + base + (k < extra ? 1 : 0);
+  }
+  if (begin) *begin = b;
+  if (end) *end = e;
+}
+
+int msm_amd_msm_range_multi(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout,
+                            const void* scalars, const void* points, size_t n, void* out96) {
+  if (!ctxs || n_ctx == 0 || !scalars || !points || !out96 || n == 0) return MSM_AMD_INPUT_ERROR;
+  const size_t sb = msm_amd_scalar_bytes(scalar_layout), pb = msm_amd_point_bytes(point_layout);
+  if (sb == 0 || pb == 0 || point_layout == MSM_AMD_POINT_PREPARED || point_layout == MSM_AMD_POINT_TABLES)
+    return MSM_AMD_INPUT_ERROR;   // (device-side layouts belong to one ctx)
+  const size_t G = std::min(n_ctx, n);
+  std::vector<const void*> sp(G), pp(G);
+  std::vector<size_t> nn(G);
+  for (size_t g = 0; g < G; ++g) {
+    size_t b, e;
+    msm_amd_shard_range(n, G, g, &b, &e);
+    sp[g] = (const uint8_t*)scalars + b * sb;
+    pp[g] = (const uint8_t*)points + b * pb;
+    nn[g] = e - b;
+  }
+  std::vector<uint8_t> partial(G * 96);
+  const int rc = batch_multi(ctxs, G, scalar_layout, point_layout, G, sp.data(), pp.data(), nn.data(), partial.data(), 0);
+  if (rc) return rc;
+  return msm_amd_sum_points(partial.data(), G, out96);
+}
+
 // ---- RCCL gather ---------------------------------------------------------------------------------------------------
 struct msm_amd_gather {
   void* lib = nullptr;

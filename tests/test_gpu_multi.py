@@ -55,6 +55,25 @@ def test_two_contexts_on_one_device_through_batch_multi(cfg, msm_pkg):
         second.close()
 
 
+def test_one_instance_split_by_point_range_over_two_contexts(cfg, msm_pkg):
+    """msm_amd_msm_range_multi: the 'single huge instance' row of SURVEY.md section 8e below the C ABI."""
+    second = msm_pkg.setup_metal_state(cfg.device())
+    try:
+        for n, layout in ((100003, msm_pkg.POINT_H2C_AFFINE), (1, msm_pkg.POINT_H2C_AFFINE), (1 << 16, msm_pkg.POINT_ARK_AFFINE)):
+            pts, sc = co.gen_instance(o.SEED_BASE + 70 + (n & 7), n)
+            want = co.msm_best(sc, pts, n)
+            if layout == msm_pkg.POINT_ARK_AFFINE:       # 72-byte records: x, y, infinity flag + padding
+                import numpy as np
+                rec = np.zeros((n, 72), dtype=np.uint8)
+                rec[:, :64] = np.frombuffer(pts, dtype=np.uint8).reshape(n, 64)
+                pts = rec.tobytes()
+            got = msm_pkg.msm_range_multi([cfg, second], sc, pts, n, point_layout=layout)
+            assert _same(got, want)
+            assert _same(msm_pkg.msm_range_multi([cfg], sc, pts, n, point_layout=layout), want)
+    finally:
+        second.close()
+
+
 def test_two_contexts_driven_from_two_python_threads(cfg, msm_pkg):
     """The header's promise: calls on one ctx are serialised, different ctxs run concurrently."""
     n = 1 << 15
@@ -119,3 +138,5 @@ def test_gpu_profiler_gpus_flag_matches_single_context():
     host, _ = _run("14", "5", "gpu", "1", "--devices", "0,0,0")
     host1, _ = _run("14", "5", "gpu", "1")
     assert host["results_fnv1a64"] == host1["results_fnv1a64"]
+    ranged, _ = _run("14", "5", "gpu", "1", "--devices", "0,0,0", "--range-split")     # every instance over 3 contexts
+    assert ranged["results_fnv1a64"] == host1["results_fnv1a64"]
