@@ -53,6 +53,7 @@ def main():
     pool[special] = (dp, ds, o.decode_jacobian_mont_le(co.msm_best(sb, pb, n_sp)))
     host[special] = (pb, sb)
     keys = sizes + [special]
+    second = m.setup_metal_state(cfg.device())        # a second context on the same device (multi-context entry points)
     size_of = lambda k: abs(k)                        # noqa: E731
     checked = 0
     for r in range(a.rounds):
@@ -78,8 +79,14 @@ def main():
                     out = cfg.msm_batch_device([pool[n][1]], [pool[n][0]], [size_of(n)])[0]
                 elif mode < 0.7:
                     out = m.gpu_msm_h2c(host[n][1], host[n][0], cfg)
-                elif mode < 0.85:
+                elif mode < 0.8:
                     out = m.msm_best(host[n][1], host[n][0], cfg)
+                elif mode < 0.88:                     # ONE instance over two contexts by point range
+                    out = m.msm_range_multi([cfg, second], host[n][1], host[n][0], size_of(n))
+                elif mode < 0.94:                     # the instance loop over two contexts
+                    out = m.msm_batch_multi([cfg, second], [host[n][1]] * 3, [host[n][0]] * 3, [size_of(n)] * 3)
+                    assert out[0] == out[1] == out[2]
+                    out = out[0]
                 else:                                 # a host-slice batch of three
                     out = cfg.msm_batch([host[n][1]] * 3, [host[n][0]] * 3, [size_of(n)] * 3)
                     assert out[0] == out[1] == out[2]
@@ -89,6 +96,7 @@ def main():
             assert o.decode_jacobian_mont_le(out) == pool[n][2], ("lone", r, n, parts)
             checked += 1
     cfg.set_window_size(0)
+    second.close()
     print(f"soak ok: {a.rounds} rounds, {checked} MSMs checked against the oracle")
 
 
