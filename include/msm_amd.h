@@ -430,7 +430,10 @@ enum {
   MSM_AMD_OP_FP29_LOCKSTEP_PAIR = 33, /* a * b + b * b        (two products side by side) */
   MSM_AMD_OP_FP29_LOCKSTEP_MIX = 34,  /* 2 a b + 2 a^2 + b^2  (double product next to a product, squaring pair) */
   MSM_AMD_OP_FP29_LOCKSTEP_TRIPLE = 35, /* a b + a^2 + b^2    (three products side by side) */
-  MSM_AMD_OP_FP29_MUL2_KARATSUBA = 36 /* 2 a b                (schoolbook + Karatsuba product, one reduction) */
+  MSM_AMD_OP_FP29_MUL2_KARATSUBA = 36, /* 2 a b               (schoolbook + Karatsuba product, one reduction) */
+  /* host only again: the inversion of the CPU tail (normalisation of every result, batched-affine CPU MSM) */
+  MSM_AMD_OP_H64_FP_INV = 37,        /* a^-1 by the binary GCD with 31-step rounds; 0 -> 0; b ignored */
+  MSM_AMD_OP_H64_FP_INV_FERMAT = 38  /* a^(p-2), its checker */
 };
 int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count);
 /* The same operation bodies executed on the host CPU (no GPU needed): host-logic tests. */

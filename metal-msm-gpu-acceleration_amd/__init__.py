@@ -25,7 +25,7 @@ POINT_BYTES = {POINT_H2C_AFFINE: 64, POINT_ARK_PROJECTIVE: 96, POINT_ARK_AFFINE:
  OP_FP29_SUB_K8E30, OP_FP29_SUB_K8E31, OP_FP29_SUB_K16E30, OP_FP29_SUB_K16E31, OP_FP29_ROUNDTRIP, OP_EC29_MADD,
  OP_EC29_ADD, OP_EC29_MADD_CHAIN, OP_EC29_ADD_CHAIN, OP_EC29_MMADD, OP_H64_FP_MUL, OP_H64_FP_ADD, OP_H64_FP_SUB,
  OP_H64_EC_ADD, OP_H64_EC_DBL, OP_FP29_MUL_KARATSUBA, OP_FP29_LOCKSTEP_PAIR, OP_FP29_LOCKSTEP_MIX,
- OP_FP29_LOCKSTEP_TRIPLE, OP_FP29_MUL2_KARATSUBA) = range(37)
+ OP_FP29_LOCKSTEP_TRIPLE, OP_FP29_MUL2_KARATSUBA, OP_H64_FP_INV, OP_H64_FP_INV_FERMAT) = range(39)
 
 
 def op_is_point(op):

@@ -195,10 +195,38 @@ MSM_IFMA inline void to_words(const V5& a, __m512i w[4]) {   // a < 2^256, limbs
   w[3] = _mm512_or_si512(_mm512_srli_epi64(a.l[3], 36), _mm512_slli_epi64(a.l[4], 16));
 }
 
-// eight records of 8 u64 (x words 0..3, y words 4..7) at base + 8 * idx[k]  ->  x, y
-MSM_IFMA inline void gather_xy(const uint64_t* base, __m512i idx8, V5& x, V5& y) {
-  __m512i w[8];
-  for (int j = 0; j < 8; ++j) w[j] = _mm512_i64gather_epi64(idx8, (const long long*)(base + j), 8);
+// 8 x 8 transpose of u64: in[k] = record k (8 words)  ->  out[j] = word j of the eight records (and back: the
+// transpose is its own inverse).  8 unpacks + 16 lane shuffles; the hardware gather of the same 64 words costs about twice as
+// much on Zen 4 / 5, a scatter more.
+MSM_IFMA inline void transpose8(const __m512i in[8], __m512i out[8]) {
+  __m512i a[8], b[8];
+  for (int i = 0; i < 8; i += 2) {
+    a[i] = _mm512_unpacklo_epi64(in[i], in[i + 1]);
+    a[i + 1] = _mm512_unpackhi_epi64(in[i], in[i + 1]);
+  }
+  b[0] = _mm512_shuffle_i64x2(a[0], a[2], 0x88);
+  b[1] = _mm512_shuffle_i64x2(a[0], a[2], 0xDD);
+  b[2] = _mm512_shuffle_i64x2(a[4], a[6], 0x88);
+  b[3] = _mm512_shuffle_i64x2(a[4], a[6], 0xDD);
+  b[4] = _mm512_shuffle_i64x2(a[1], a[3], 0x88);
+  b[5] = _mm512_shuffle_i64x2(a[1], a[3], 0xDD);
+  b[6] = _mm512_shuffle_i64x2(a[5], a[7], 0x88);
+  b[7] = _mm512_shuffle_i64x2(a[5], a[7], 0xDD);
+  out[0] = _mm512_shuffle_i64x2(b[0], b[2], 0x88);
+  out[4] = _mm512_shuffle_i64x2(b[0], b[2], 0xDD);
+  out[2] = _mm512_shuffle_i64x2(b[1], b[3], 0x88);
+  out[6] = _mm512_shuffle_i64x2(b[1], b[3], 0xDD);
+  out[1] = _mm512_shuffle_i64x2(b[4], b[6], 0x88);
+  out[5] = _mm512_shuffle_i64x2(b[4], b[6], 0xDD);
+  out[3] = _mm512_shuffle_i64x2(b[5], b[7], 0x88);
+  out[7] = _mm512_shuffle_i64x2(b[5], b[7], 0xDD);
+}
+
+// eight records of 8 u64 (x words 0..3, y words 4..7), record k at base + 8 * idx[k]  ->  x, y
+MSM_IFMA inline void gather_xy(const uint64_t* base, const uint64_t idx[8], V5& x, V5& y) {
+  __m512i rec[8], w[8];
+  for (int k = 0; k < 8; ++k) rec[k] = _mm512_loadu_si512(base + 8 * idx[k]);
+  transpose8(rec, w);
   x = from_words(w);
   y = from_words(w + 4);
 }
@@ -277,11 +305,13 @@ MSM_IFMA void test_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* ou
 // negated when bit 31 of pt_idx[k] is set, to bucket buckets[8 * bucket_idx[k] ..].
 // Computes d = x2 - x1 and the running products of eight interleaved chains (lane = k mod 8); returns the eight chain
 // totals (Q domain, canonical, 4 x u64 each).  All coordinates Q domain, canonical; x2 != x1 for every element.
-MSM_IFMA void forward(const uint64_t* buckets, const uint32_t* bucket_idx, const uint64_t* pts, const uint32_t* pt_idx,
-                      int count, Scratch& ws, uint64_t totals[8][4]) {
+MSM_IFMA int forward(const uint64_t* buckets, const uint32_t* bucket_idx, const uint64_t* pts, const uint32_t* pt_idx,
+                     int count, Scratch& ws, uint64_t totals[8][4]) {
   const Consts& K = consts();
   const int rows = (count + 7) / 8;
   ws.rows = rows;
+  ws.n_special = 0;
+  std::memset(ws.is_special, 0, (size_t)count);
   const V5 one = bcast(K.one_q52);
   V5* X1 = (V5*)ws.x1;
   V5* Y1 = (V5*)ws.y1;
@@ -296,18 +326,30 @@ MSM_IFMA void forward(const uint64_t* buckets, const uint32_t* bucket_idx, const
     alignas(64) uint64_t bi[8], pi[8], sg[8];
     for (int k = 0; k < 8; ++k) {
       const int e = k < live ? base + k : base;
-      bi[k] = (uint64_t)bucket_idx[e] * 8u;
-      pi[k] = (uint64_t)(pt_idx[e] & 0x7FFFFFFFu) * 8u;
+      bi[k] = (uint64_t)bucket_idx[e];
+      pi[k] = (uint64_t)(pt_idx[e] & 0x7FFFFFFFu);
       sg[k] = (uint64_t)0 - (uint64_t)(pt_idx[e] >> 31);
     }
-    gather_xy(buckets, _mm512_load_si512(bi), X1[r], Y1[r]);
+    gather_xy(buckets, bi, X1[r], Y1[r]);
     V5 y2;
-    gather_xy(pts, _mm512_load_si512(pi), X2[r], y2);
+    gather_xy(pts, pi, X2[r], y2);
     const __mmask8 negate = _mm512_cmpneq_epi64_mask(_mm512_load_si512(sg), _mm512_setzero_si512());
     const V5 ny = neg_canon(y2, K);
     for (int i = 0; i < 5; ++i) Y2[r].l[i] = _mm512_mask_blend_epi64(negate, y2.l[i], ny.l[i]);
     V5 d = sub2p(X2[r], X1[r], K);
-    for (int i = 0; i < 5; ++i) d.l[i] = _mm512_mask_blend_epi64(m, one.l[i], d.l[i]);
+    // x2 = x1: the same point again or its negative -- not a chord addition.  The lane computes with d = 1 and the
+    // element is reported back (the caller routes the point to the bucket's Jacobian side accumulator).
+    const __m512i any = _mm512_or_si512(_mm512_or_si512(_mm512_or_si512(d.l[0], d.l[1]), _mm512_or_si512(d.l[2], d.l[3])), d.l[4]);
+    const __mmask8 zero_d = (__mmask8)(_mm512_cmpeq_epi64_mask(any, _mm512_setzero_si512()) & m);
+    if (zero_d) {
+      for (int k = 0; k < live; ++k)
+        if ((zero_d >> k) & 1) {
+          ws.special[ws.n_special++] = base + k;
+          ws.is_special[base + k] = 1;
+        }
+    }
+    const __mmask8 keep = (__mmask8)(m & ~zero_d);
+    for (int i = 0; i < 5; ++i) d.l[i] = _mm512_mask_blend_epi64(keep, one.l[i], d.l[i]);
     D[r] = d;
     PRE[r] = r ? mont(PRE[r - 1], d, K) : d;
   }
@@ -318,6 +360,7 @@ MSM_IFMA void forward(const uint64_t* buckets, const uint32_t* bucket_idx, const
   for (int j = 0; j < 4; ++j) _mm512_store_si512(buf[j], w[j]);
   for (int k = 0; k < 8; ++k)
     for (int j = 0; j < 4; ++j) totals[k][j] = buf[j][k];
+  return ws.n_special;
 }
 
 // Backward pass: inv[k] = 1 / totals[k] (Q domain).  Writes the sums back into the buckets.
@@ -347,11 +390,12 @@ MSM_IFMA void backward(uint64_t* buckets, const uint32_t* bucket_idx, int count,
     const V5 y3 = sub2p(mont(lam, e, K), Y1[r], K);
     to_words(canon(x3, K), w);
     to_words(canon(y3, K), w + 4);
-    for (int j = 0; j < 8; ++j) _mm512_store_si512(buf[j], w[j]);
+    __m512i rec[8];
+    transpose8(w, rec);
     const int base = 8 * r, live = count - base < 8 ? count - base : 8;
     for (int k = 0; k < live; ++k) {
-      uint64_t* dst = buckets + (size_t)bucket_idx[base + k] * 8;
-      for (int j = 0; j < 8; ++j) dst[j] = buf[j][k];
+      // (an element with x2 = x1 computed with d = 1: its bucket keeps its value)
+      if (!ws.is_special[base + k]) _mm512_storeu_si512(buckets + (size_t)bucket_idx[base + k] * 8, rec[k]);
     }
   }
 }

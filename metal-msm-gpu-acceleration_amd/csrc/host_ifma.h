@@ -15,6 +15,9 @@ struct Scratch {
   alignas(64) uint64_t x1[kMaxRows * 40], y1[kMaxRows * 40], x2[kMaxRows * 40], y2[kMaxRows * 40], d[kMaxRows * 40],
       pre[kMaxRows * 40];
   int rows = 0;
+  int n_special = 0;            // elements of the batch with x2 = x1 (forward reports them, backward leaves their buckets alone)
+  int special[kMaxBatch];
+  uint8_t is_special[kMaxBatch];
 };
 
 bool available();
@@ -22,8 +25,9 @@ bool available();
 void test_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count);   // CPUID: AVX-512 F / IFMA / DQ / VL / BW
 void convert(const uint64_t* in, uint64_t* out, size_t n, int dir);   // dir 0: R (2^256) -> Q (2^260) domain, 1: back
 // pt_idx[k]: index of the point in `pts` (8 u64 per point), bit 31 set = add the negative
-void forward(const uint64_t* buckets, const uint32_t* bucket_idx, const uint64_t* pts, const uint32_t* pt_idx, int count,
-             Scratch& ws, uint64_t totals[8][4]);
+// returns the number of elements whose point has the x of its bucket (ws.special[]: not added, see host_msm.hip)
+int forward(const uint64_t* buckets, const uint32_t* bucket_idx, const uint64_t* pts, const uint32_t* pt_idx, int count,
+            Scratch& ws, uint64_t totals[8][4]);
 void backward(uint64_t* buckets, const uint32_t* bucket_idx, int count, Scratch& ws, const uint64_t inv[8][4]);
 
 }  // namespace ifma

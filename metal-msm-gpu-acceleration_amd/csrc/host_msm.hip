@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -117,13 +118,16 @@ struct Barrier {   // the team meets here between phases; short waits, so spin (
 };
 
 // Buckets of one phase-1 task: affine value + occupancy + Jacobian side accumulator (z = 0: empty).
-struct BucketSet {
-  std::vector<Aff> aff;
-  std::vector<uint8_t> full;
-  std::vector<Jac> side;
-  std::vector<uint32_t> stamp;   // id of the batch in which the bucket has a pending addition
+struct BucketSet {   // aff / stamp / full: nbuckets entries each inside the call's scratch block (run())
+  Aff* aff = nullptr;
+  uint32_t* stamp = nullptr;   // id of the batch in which the bucket has a pending addition
+  uint8_t* full = nullptr;
+  std::vector<Jac> side;       // allocated on the first collision only
   bool any_side = false;
 };
+constexpr size_t bucket_set_bytes(size_t nbuckets) {
+  return ((nbuckets * (sizeof(Aff) + sizeof(uint32_t) + 1)) + 63) & ~(size_t)63;
+}
 
 constexpr int kBatch = 1024;
 static_assert(kBatch <= ifma::kMaxBatch, "the vector path's scratch holds a whole batch");
@@ -211,20 +215,17 @@ void flush(BucketSet& B, Pending& q) {
 // inversion costs ~380 multiplications.
 void fill_buckets(BucketSet& B, Pending& q, const int16_t* digits, const Aff* points, size_t lo, size_t hi,
                   uint32_t nbuckets, int batch) {
-  B.aff.resize(nbuckets);
-  B.full.assign(nbuckets, 0);
-  B.stamp.assign(nbuckets, batch ? 0u : 1u);   // batch == 0: every bucket looks "pending" -> Jacobian path
+  std::memset(B.full, 0, nbuckets);
+  std::fill(B.stamp, B.stamp + nbuckets, batch ? 0u : 1u);   // batch == 0: every bucket looks "pending" -> Jacobian path
   B.side.clear();
   B.any_side = false;
   uint32_t batch_id = 1;
   q.count = 0;
   for (size_t i = lo; i < hi; ++i) {
     const int32_t d = digits[i];
-    if (d == 0) continue;
-    const Aff& src = points[i];
-    if (h64::is_zero(src.x) && h64::is_zero(src.y)) continue;   // affine identity (0, 0)
+    if (d == 0) continue;   // (also every digit of an identity point: phase 0)
     const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
-    Aff p = src;
+    Aff p = points[i];
     if (d < 0) p.y = fe_neg(p.y);
     if (B.stamp[b] == batch_id) {   // its bucket already has an addition pending in this batch
       if (!B.any_side) {
@@ -271,26 +272,37 @@ Fe pow2_mod_p(unsigned k) {   // 2^k mod p as a plain integer below p
   return v;
 }
 
-void flush_ifma(BucketSet& B, Pending& q, IfmaState& st, const Aff* points_q) {
-  if (q.count == 0) return;
+thread_local uint64_t tl_cycles[4];   // MSM_AMD_HOST_TRACE: forward / inversion / backward / whole flush, in TSC ticks
+// Returns the number of elements the vector code did NOT add because the point has its bucket's x (st.scratch.special[]).
+int flush_ifma(BucketSet& B, Pending& q, IfmaState& st, const Aff* points_q) {
+  if (q.count == 0) return 0;
   uint64_t totals[8][4], inv[8][4];
-  ifma::forward((const uint64_t*)B.aff.data(), q.bucket, (const uint64_t*)points_q, st.pt_idx, q.count, st.scratch, totals);
+  const uint64_t c0 = __builtin_ia32_rdtsc();
+  const int specials = ifma::forward((const uint64_t*)B.aff, q.bucket, (const uint64_t*)points_q, st.pt_idx, q.count, st.scratch, totals);
   // 1 / totals[k] in the Q domain: with X = totals[k] read as an R-domain element, inv(X) = R^2 / X and
   // mul(R^2 / X, 2^264) = Q^2 / X = (T Q)^-1 Q^2 = T^-1 Q.  One inversion for the eight of them.
+  const uint64_t c1 = __builtin_ia32_rdtsc();
   Fe x[8], pre[8];
   for (int k = 0; k < 8; ++k) {
     std::memcpy(&x[k], totals[k], 32);
     pre[k] = k ? h64::mul(pre[k - 1], x[k]) : x[k];
   }
-  Fe run = h64::inv(pre[7]);
+  static const bool fermat = std::getenv("MSM_AMD_HOST_INV_FERMAT") != nullptr;   // A/B aid
+  Fe run = fermat ? h64::inv_fermat(pre[7]) : h64::inv(pre[7]);
   for (int k = 7; k >= 0; --k) {
     const Fe xi = k ? h64::mul(run, pre[k - 1]) : run;
     if (k) run = h64::mul(run, x[k]);
     const Fe r = h64::mul(xi, st.to_q);
     std::memcpy(inv[k], &r, 32);
   }
-  ifma::backward((uint64_t*)B.aff.data(), q.bucket, q.count, st.scratch, inv);
+  const uint64_t c2 = __builtin_ia32_rdtsc();
+  ifma::backward((uint64_t*)B.aff, q.bucket, q.count, st.scratch, inv);
+  const uint64_t c3 = __builtin_ia32_rdtsc();
+  tl_cycles[0] += c1 - c0;
+  tl_cycles[1] += c2 - c1;
+  tl_cycles[2] += c3 - c2;
   q.count = 0;
+  return specials;
 }
 
 // fill_buckets with the batched additions on the vector unit.  `points` (R domain) still feeds the Jacobian side
@@ -299,9 +311,9 @@ void flush_ifma(BucketSet& B, Pending& q, IfmaState& st, const Aff* points_q) {
 // so every addition in a batch is a generic one.
 void fill_buckets_ifma(BucketSet& B, Pending& q, IfmaState& st, const int16_t* digits, const Aff* points, const Aff* points_q,
                        size_t lo, size_t hi, uint32_t nbuckets, int batch) {
-  B.aff.assign(nbuckets, Aff{});
-  B.full.assign(nbuckets, 0);
-  B.stamp.assign(nbuckets, 0u);
+  std::memset((void*)B.aff, 0, nbuckets * sizeof(Aff));
+  std::memset(B.full, 0, nbuckets);
+  std::memset(B.stamp, 0, nbuckets * sizeof(uint32_t));
   B.side.clear();
   B.any_side = false;
   uint32_t batch_id = 1;
@@ -325,30 +337,32 @@ void fill_buckets_ifma(BucketSet& B, Pending& q, IfmaState& st, const int16_t* d
   retry.clear();
   again.clear();
   const size_t retry_cap = (size_t)batch;
+  static const bool prefetch = std::getenv("MSM_AMD_HOST_NO_PREFETCH") == nullptr;   // A/B aid
   auto add_one = [&](uint32_t i, bool may_wait) {
     const int32_t d = digits[i];
-    const Aff& src = points[i];
     const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
     if (B.stamp[b] == batch_id) {
       if (may_wait && retry.size() < retry_cap) retry.push_back(i);
-      else to_side(b, src, d < 0);
+      else to_side(b, points[i], d < 0);
       return;
     }
-    const Aff& pq = points_q[i];
     if (!B.full[b]) {
+      const Aff& pq = points_q[i];
       B.aff[b] = pq;
       if (d < 0) B.aff[b].y = fe_neg(pq.y);
       B.full[b] = 1;
       return;
     }
-    if (fe_eq(B.aff[b].x, pq.x)) {   // same x: doubling or cancellation -- not an affine chord addition
-      to_side(b, src, d < 0);
-      return;
-    }
+    // (a point with its bucket's x -- doubling or cancellation, not a chord addition -- is found by the vector code
+    // from its zero denominator and comes back through flush_ifma's return value)
     B.stamp[b] = batch_id;
     q.bucket[q.count] = b;
     st.pt_idx[q.count] = i | (d < 0 ? 0x80000000u : 0u);   // the vector code gathers and negates the point itself
     ++q.count;
+    if (prefetch) {   // both records are first read by the vector forward pass, a batch later
+      __builtin_prefetch(&B.aff[b], 0, 3);
+      __builtin_prefetch(&points_q[i], 0, 3);
+    }
   };
   size_t i = lo;
   for (;;) {
@@ -363,10 +377,7 @@ void fill_buckets_ifma(BucketSet& B, Pending& q, IfmaState& st, const int16_t* d
         from_waiting += q.count - before;
       } else if (i < hi) {
         const uint32_t idx = (uint32_t)i++;
-        const int32_t d = digits[idx];
-        if (d == 0) continue;
-        const Aff& src = points[idx];
-        if (h64::is_zero(src.x) && h64::is_zero(src.y)) continue;   // affine identity (0, 0)
+        if (digits[idx] == 0) continue;   // (also every digit of an identity point: phase 0)
         add_one(idx, true);
       } else {
         break;
@@ -382,13 +393,17 @@ void fill_buckets_ifma(BucketSet& B, Pending& q, IfmaState& st, const int16_t* d
       retry.clear();
     }
     if (q.count == 0 && again.empty() && retry.empty() && i >= hi) break;
-    flush_ifma(B, q, st, points_q);
+    const int specials = flush_ifma(B, q, st, points_q);
+    for (int e = 0; e < specials; ++e) {   // q.bucket / st.pt_idx still hold the batch
+      const int at = st.scratch.special[e];
+      to_side(q.bucket[at], points[st.pt_idx[at] & 0x7FFFFFFFu], (st.pt_idx[at] >> 31) != 0);
+    }
     ++batch_id;
     for (uint32_t idx : retry) again.push_back(idx);   // `again` may still hold entries when the batch filled up first
     retry.clear();
   }
   // back to the R domain for phase 2 (empty slots are converted along; nobody reads them)
-  ifma::convert((const uint64_t*)B.aff.data(), (uint64_t*)B.aff.data(), (size_t)nbuckets * 2, 1);
+  ifma::convert((const uint64_t*)B.aff, (uint64_t*)B.aff, (size_t)nbuckets * 2, 1);
 }
 
 // One phase-2 task: sum_{b in [lo, hi)} (b + 1) B_b where B_b is the sum over the window's point groups, by running
@@ -442,7 +457,9 @@ int batch_for(uint32_t c, size_t points_per_task, bool vec = false) {
   // scalar path: a quarter of the buckets (a collision costs a Jacobian addition); vector path: half of them (a
   // collision only waits for the next batch)
   const size_t nbk = (size_t)1 << (c - 1);
-  const int batch = (int)std::min<size_t>(vec ? kBatch : kBatch / 2, vec ? nbk / 2 : nbk / 4);
+  // (vector path: 1024 per inversion measured no better than 512 once the inversion is the binary GCD -- 2^18 points 32.0
+  // vs 29.2 ms, 2^20 88.4 vs 87.5 -- and the batch's scratch is half the size: profiles/r03_cpu_msm_steps.txt)
+  const int batch = (int)std::min<size_t>(kBatch / 2, vec ? nbk / 2 : nbk / 4);
   if (batch < 8 || points_per_task < (size_t)4 * batch) return 0;
   const double nb = (double)nbk;
   const double cost = vec ? kVecAdd + 384.0 / batch : 6.0 + 384.0 / batch + 11.0 * batch / (2.0 * nb);
@@ -476,7 +493,49 @@ Choice window_for(size_t n, int threads, bool vec = false) {
   return best;
 }
 
-Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n, int threads) {
+// The two arrays of n entries (digit matrix, points in the vector code's domain) live in ONE process-wide scratch
+// block that outlives the call: a std::vector would zero 106 MB on the calling thread at 2^20 points -- fresh pages from
+// mmap every call, 36 ms of page faults next to 87 ms of arithmetic -- where the workers of phase 0 overwrite every
+// entry anyway.  A concurrent second call (the block is leased under try_lock) takes plain uninitialised memory of its
+// own; blocks above kScratchKeep are returned to the system after the call.
+constexpr size_t kScratchKeep = (size_t)1 << 30;
+struct ScratchBlock {
+  std::mutex m;
+  void* p = nullptr;
+  size_t cap = 0;
+};
+ScratchBlock g_scratch;
+struct ScratchLease {
+  void* p = nullptr;
+  bool shared = false;
+  explicit ScratchLease(size_t bytes) {
+    if (g_scratch.m.try_lock()) {
+      shared = true;
+      if (g_scratch.cap < bytes) {
+        std::free(g_scratch.p);
+        g_scratch.p = std::aligned_alloc(64, (bytes + 63) & ~(size_t)63);
+        g_scratch.cap = g_scratch.p ? bytes : 0;
+      }
+      p = g_scratch.p;
+    } else {
+      p = std::aligned_alloc(64, (bytes + 63) & ~(size_t)63);
+    }
+  }
+  ~ScratchLease() {
+    if (!shared) {
+      std::free(p);
+      return;
+    }
+    if (g_scratch.cap > kScratchKeep) {
+      std::free(g_scratch.p);
+      g_scratch.p = nullptr;
+      g_scratch.cap = 0;
+    }
+    g_scratch.m.unlock();
+  }
+};
+
+Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n, int threads, bool& ok) {
   const int T = std::max(1, std::min<int>(threads, (int)std::min<size_t>((n + 63) / 64, 256)));
   const bool vec = ifma::available() && std::getenv("MSM_AMD_HOST_NO_IFMA") == nullptr;
   Choice choice = window_for(n, T, vec);
@@ -490,16 +549,33 @@ Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n,
   }
   if (std::getenv("MSM_AMD_HOST_WINDOW") || std::getenv("MSM_AMD_HOST_GROUPS"))
     choice.batch = batch_for(choice.c, n / choice.groups, vec);
+  if (const char* e = std::getenv("MSM_AMD_HOST_BATCH")) {
+    const int v = std::atoi(e);
+    if (v >= 8 && v <= kBatch && choice.batch) choice.batch = std::min(choice.batch, v);
+  }
   const bool use_vec = vec && choice.batch != 0;
   const uint32_t c = choice.c, groups = choice.groups;
   const uint32_t W = 254 / c + 1;
   const uint32_t half = 1u << (c - 1);   // buckets per window: slot b <-> digit magnitude b + 1
   const uint32_t segs = segments_for(c, groups, T);   // phase-2 tasks per window
   const uint32_t seg_len = (half + segs - 1) / segs;
-  std::vector<int16_t> digits((size_t)W * n);
-  std::vector<Aff> points_q(use_vec ? n : 0);   // the points in the vector code's Montgomery domain
+  const size_t digit_bytes = ((size_t)W * n * sizeof(int16_t) + 63) & ~(size_t)63;
+  const size_t pointq_bytes = use_vec ? n * sizeof(Aff) : 0, set_bytes = bucket_set_bytes(half);
+  ScratchLease lease(digit_bytes + pointq_bytes + (size_t)W * groups * set_bytes);
+  if (!lease.p) {   // out of host memory: reported, not thrown across the C ABI
+    ok = false;
+    return jac_identity();
+  }
+  int16_t* const digits = (int16_t*)lease.p;                       // [W][n], written by phase 0
+  Aff* const points_q = (Aff*)((uint8_t*)lease.p + digit_bytes);   // the points in the vector code's Montgomery domain
   const Fe to_q = pow2_mod_p(264);
   std::vector<BucketSet> sets((size_t)W * groups);
+  for (size_t t = 0; t < sets.size(); ++t) {   // (first written by the worker that takes task t)
+    uint8_t* at = (uint8_t*)lease.p + digit_bytes + pointq_bytes + t * set_bytes;
+    sets[t].aff = (Aff*)at;
+    sets[t].stamp = (uint32_t*)(at + (size_t)half * sizeof(Aff));
+    sets[t].full = at + (size_t)half * (sizeof(Aff) + sizeof(uint32_t));
+  }
   std::vector<Jac> part((size_t)W * segs);
   std::atomic<size_t> next0{0}, next1{0}, next2{0};
   Barrier barrier(T);
@@ -526,6 +602,7 @@ Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n,
           k = scalars[i];
           for (int t = 0; t < 5; ++t) k = Fr::reduce_once(k);
         }
+        if (h64::is_zero(points[i].x) && h64::is_zero(points[i].y)) k = u256_zero();   // affine identity (0, 0): no digits
         uint32_t carry = 0;
         for (uint32_t w = 0; w < W; ++w) {
           const uint32_t start = w * c;
@@ -539,11 +616,13 @@ Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n,
           digits[(size_t)w * n + i] = (int16_t)d;
         }
       }
-      if (use_vec) ifma::convert((const uint64_t*)(points + lo), (uint64_t*)(points_q.data() + lo), (hi - lo) * 2, 0);
+      if (use_vec) ifma::convert((const uint64_t*)(points + lo), (uint64_t*)(points_q + lo), (hi - lo) * 2, 0);
     }
     barrier.wait();
     if (tid == 0) stamp("digits");
     // ---- phase 1: tasks (window, point group)
+    tl_cycles[0] = tl_cycles[1] = tl_cycles[2] = 0;
+    const uint64_t phase1_begin = __builtin_ia32_rdtsc();
     {
       Pending* q = new Pending();
       IfmaState* vs = use_vec ? new IfmaState() : nullptr;
@@ -554,15 +633,21 @@ Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n,
         const uint32_t w = (uint32_t)(t / groups), g = (uint32_t)(t % groups);
         const size_t p_lo = n * g / groups, p_hi = n * (g + 1) / groups;
         if (use_vec)
-          fill_buckets_ifma(sets[t], *q, *vs, &digits[(size_t)w * n], points, points_q.data(), p_lo, p_hi, half, choice.batch);
+          fill_buckets_ifma(sets[t], *q, *vs, &digits[(size_t)w * n], points, points_q, p_lo, p_hi, half, choice.batch);
         else
           fill_buckets(sets[t], *q, &digits[(size_t)w * n], points, p_lo, p_hi, half, choice.batch);
       }
       delete vs;
       delete q;
     }
+    const uint64_t phase1_ticks = __builtin_ia32_rdtsc() - phase1_begin;
     barrier.wait();
     if (tid == 0) stamp("buckets");
+    if (tid == 0 && trace && use_vec)
+      std::fprintf(stderr, "host_msm: thread 0 of phase 1: %.1f %% vector forward, %.1f %% inversion, %.1f %% vector backward, "
+                   "%.1f %% scheduling and the rest\n", 100.0 * tl_cycles[0] / phase1_ticks, 100.0 * tl_cycles[1] / phase1_ticks,
+                   100.0 * tl_cycles[2] / phase1_ticks,
+                   100.0 * (phase1_ticks - tl_cycles[0] - tl_cycles[1] - tl_cycles[2]) / phase1_ticks);
     // ---- phase 2: tasks (window, bucket segment)
     for (;;) {
       const size_t t = next2.fetch_add(1, std::memory_order_relaxed);
@@ -591,9 +676,11 @@ Jacobian run(const u256* scalars, int scalars_mont, const Aff* points, size_t n,
 
 // sum_i k_i * P_i on `threads` host threads.  scalars: 32-byte LE (Montgomery if scalars_mont), points: 64-byte
 // affine Montgomery LE with (0,0) = identity.  The result is NOT normalised (callers add it to a GPU partial first).
-Jacobian host_msm(const u256* scalars, int scalars_mont, const Affine* points, size_t n, int threads) {
-  if (n == 0) return jac_identity();
-  return run(scalars, scalars_mont, (const Aff*)points, n, threads);
+Jacobian host_msm(const u256* scalars, int scalars_mont, const Affine* points, size_t n, int threads, bool* ok) {
+  bool fine = true;
+  const Jacobian r = n == 0 ? jac_identity() : run(scalars, scalars_mont, (const Aff*)points, n, threads, fine);
+  if (ok) *ok = fine;
+  return r;
 }
 
 }  // namespace msm_amd
@@ -609,7 +696,9 @@ int msm_amd_host_msm(int scalar_layout, int point_layout, const void* scalars, c
   if (point_layout != MSM_AMD_POINT_H2C_AFFINE) return MSM_AMD_INPUT_ERROR;
   if (scalar_layout != MSM_AMD_SCALAR_MONT_LE && scalar_layout != MSM_AMD_SCALAR_CANON_LE) return MSM_AMD_INPUT_ERROR;
   if (threads <= 0) threads = msm_amd_host_threads();
-  const Jacobian r = host_msm((const u256*)scalars, scalar_layout == MSM_AMD_SCALAR_MONT_LE, (const Affine*)points, n, threads);
+  bool ok = true;
+  const Jacobian r = host_msm((const u256*)scalars, scalar_layout == MSM_AMD_SCALAR_MONT_LE, (const Affine*)points, n, threads, &ok);
+  if (!ok) return MSM_AMD_PIPELINE_ERROR;   // host allocation failed
   const h64::Jac nrm = h64::normalise(h64::load(r));
   std::memcpy(out96, &nrm, 96);
   return MSM_AMD_OK;

@@ -113,6 +113,6 @@ void launch_filter_scatter(hipStream_t st, const u256* scalars, const Affine* po
 void launch_test_op(hipStream_t st, int op, const u256* a, const u256* b, u256* out, uint32_t count);
 
 // host_msm.hip (host code only)
-Jacobian host_msm(const u256* scalars, int scalars_mont, const Affine* points, size_t n, int threads);
+Jacobian host_msm(const u256* scalars, int scalars_mont, const Affine* points, size_t n, int threads, bool* ok = nullptr);   // *ok = false: host allocation failed
 
 }  // namespace msm_amd

@@ -1943,7 +1943,8 @@ int msm_amd_gpu_with_cpu(msm_amd_ctx* ctx, const void* scalars, const void* poin
   Jacobian cpu_res = jac_identity();
   std::thread cpu_thread;
   const size_t n_cpu = n - split_at;
-  if (n_cpu) cpu_thread = std::thread([&] { cpu_res = host_msm(sc + split_at, 1, pt + split_at, n_cpu, cpu_threads); });
+  bool cpu_ok = true;
+  if (n_cpu) cpu_thread = std::thread([&] { cpu_res = host_msm(sc + split_at, 1, pt + split_at, n_cpu, cpu_threads, &cpu_ok); });
   Jacobian gpu_res = jac_identity();
   int rc = MSM_AMD_OK;
   if (split_at) {
@@ -1953,6 +1954,7 @@ int msm_amd_gpu_with_cpu(msm_amd_ctx* ctx, const void* scalars, const void* poin
   }
   if (n_cpu) cpu_thread.join();
   if (rc) return rc;
+  if (!cpu_ok) return fail(ctx, MSM_AMD_PIPELINE_ERROR, "gpu_with_cpu: host allocation failed in the CPU half");
   const Jacobian sum = normalise(jac_add(gpu_res, cpu_res));   // msm.rs:418-419
   std::memcpy(out96, &sum, 96);
   return MSM_AMD_OK;
@@ -1976,7 +1978,9 @@ int msm_amd_msm_best(msm_amd_ctx* ctx, const void* scalars, const void* points, 
   if (!ctx || !scalars || !points || !out96 || n == 0 || n > 0x7FFFFFFFull)
     return fail(ctx, MSM_AMD_INPUT_ERROR, "bad msm_best arguments");
   if (n < cpu_dispatch_below()) {   // explicit size dispatch as in the reference, on a ctx that owns a GPU
-    const Jacobian r = normalise(host_msm((const u256*)scalars, 1, (const Affine*)points, n, 1));
+    bool ok = true;
+    const Jacobian r = normalise(host_msm((const u256*)scalars, 1, (const Affine*)points, n, 1, &ok));
+    if (!ok) return fail(ctx, MSM_AMD_PIPELINE_ERROR, "msm_best: host allocation failed");
     std::memcpy(out96, &r, 96);
     return MSM_AMD_OK;
   }
@@ -2523,7 +2527,7 @@ static void test_op_widths(int op, size_t* wa, size_t* wb) {
 
 int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count) {
   if (!ctx || !a || !b || !out || count == 0 || op < 0 || op > kTestOpMax ||
-      (op >= MSM_AMD_OP_H64_FP_MUL && op <= MSM_AMD_OP_H64_EC_DBL))
+      (op >= MSM_AMD_OP_H64_FP_MUL && op <= MSM_AMD_OP_H64_EC_DBL))   // (host-only ops 37, 38 are above kTestOpMax)
     return fail(ctx, MSM_AMD_INPUT_ERROR, "bad test_op arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2552,17 +2556,19 @@ int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t*
   return MSM_AMD_OK;
 }
 
-// ops 27..31 exist on the host only: the 4 x 64-bit arithmetic of the CPU tail (host_fq64.h)
+// ops 27..31, 37, 38 exist on the host only: the 4 x 64-bit arithmetic of the CPU tail (host_fq64.h)
 static bool host64_test_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t count) {
-  if (op < MSM_AMD_OP_H64_FP_MUL || op > MSM_AMD_OP_H64_EC_DBL) return false;
-  const bool pt = op >= MSM_AMD_OP_H64_EC_ADD;
+  const bool inverse = op == MSM_AMD_OP_H64_FP_INV || op == MSM_AMD_OP_H64_FP_INV_FERMAT;
+  if ((op < MSM_AMD_OP_H64_FP_MUL || op > MSM_AMD_OP_H64_EC_DBL) && !inverse) return false;
+  const bool pt = op == MSM_AMD_OP_H64_EC_ADD || op == MSM_AMD_OP_H64_EC_DBL;
   for (size_t t = 0; t < count; ++t) {
     if (!pt) {
       const u256 xa = be32_to_u256(a + t * 8), xb = be32_to_u256(b + t * 8);
       h64::Fe x, y, r;
       std::memcpy(&x, &xa, 32);
       std::memcpy(&y, &xb, 32);
-      r = op == MSM_AMD_OP_H64_FP_MUL ? h64::mul(x, y) : (op == MSM_AMD_OP_H64_FP_ADD ? h64::add(x, y) : h64::sub(x, y));
+      if (inverse) r = op == MSM_AMD_OP_H64_FP_INV ? h64::inv(x) : h64::inv_fermat(x);
+      else r = op == MSM_AMD_OP_H64_FP_MUL ? h64::mul(x, y) : (op == MSM_AMD_OP_H64_FP_ADD ? h64::add(x, y) : h64::sub(x, y));
       u256 ro;
       std::memcpy(&ro, &r, 32);
       u256_to_be32(ro, out + t * 8);

@@ -159,6 +159,18 @@ def test_host64_field_and_group_ops(msm_pkg):
         msm_pkg.test_op_host(99, ja, jb, cnt)
 
 
+def test_host64_inversion_by_binary_gcd(msm_pkg):
+    """h64::inv (binary GCD with 31-step rounds on 64-bit approximations, csrc/host_fq64.h) against Python's modular
+    inverse and against the exponentiation it replaced; 0 -> 0."""
+    rng = random.Random(37)
+    a = [x for x in _vals(rng, 3000) if x] + [1 << k for k in range(0, 254, 7)] + [o.P - (1 << k) for k in range(0, 250, 11)]
+    a += [rng.randrange(1, 1 << k) for k in (8, 31, 32, 33, 62, 63, 64, 65, 96, 127, 128, 129, 190, 200)]
+    got = _run(msm_pkg, msm_pkg.OP_H64_FP_INV, a, a)
+    assert got == [pow(x, -1, o.P) for x in a]
+    assert got == _run(msm_pkg, msm_pkg.OP_H64_FP_INV_FERMAT, a, a)
+    assert _run(msm_pkg, msm_pkg.OP_H64_FP_INV, [0], [0]) == [0]
+
+
 def test_unshipped_multiplication_variants_agree(msm_pkg):
     """One Karatsuba level and the lockstep product-scanning chains (build options measured on the GPU and not shipped,
     DESIGN.md section 7) compute the same field elements as the shipped multiplication -- host twins of ops 32..36."""
