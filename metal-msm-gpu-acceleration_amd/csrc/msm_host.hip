@@ -35,7 +35,7 @@ namespace {
 constexpr uint32_t kModulusBits = 254;   // limbs_conversion.rs:172, :344
 constexpr uint32_t kMinWindow = 3, kMaxWindow = 17;   // u16 digits up to 15, u32 digits for 16 and 17
 constexpr uint32_t kDefaultBallot = 1;                // sort ranking (Plan::ballot), chosen by profiles/r02_sort_ranking_ab.txt
-constexpr size_t kCpuDispatchBelow = 5;               // msm_best: see cpu_dispatch_below()
+constexpr size_t kCpuDispatchBelow = 17;              // msm_best: see cpu_dispatch_below()
 
 struct DeviceBuf {
   void* p = nullptr;
@@ -1961,8 +1961,9 @@ int msm_amd_gpu_with_cpu(msm_amd_ctx* ctx, const void* scalars, const void* poin
 }
 
 // msm_best's size dispatch (msm.rs:440-444: `if n < 2^17 { cpu } else { gpu }`), threshold measured on MI355X with
-// tools/crossover.py (profiles/r02_crossover.txt): one blocking GPU call costs ~0.35 ms of launches, event waits and
-// host Horner whatever n is; the single-threaded host bucket method is faster than that only for a handful of points.
+// tools/crossover.py (profiles/r03_crossover.txt; round 2: r02_crossover.txt, 5 points): one blocking GPU call costs
+// 0.28-0.38 ms of launches, event waits and host Horner whatever n is; the single-threaded host bucket method is faster
+// than that up to 16 points (0.34 against 0.38 ms).
 static size_t cpu_dispatch_below() {
   static const size_t v = [] {
     if (const char* e = std::getenv("MSM_AMD_CPU_BELOW")) return (size_t)std::strtoull(e, nullptr, 10);
