@@ -535,17 +535,21 @@ Jacobian normalise(const Jacobian& p) { return h64::store(h64::normalise(h64::lo
 // Replaces sum_reduction_final + final_accumulation.rs:19-39.
 Jacobian host_combine(const Jacobian* partial, const Plan& p) {
   const uint32_t top = p.c * (p.W - 1) + p.lb;   // highest bit position in use
-  std::vector<std::vector<const Jacobian*>> at(top + 1);
-  for (uint32_t w = 0; w < p.W; ++w) {
-    const Jacobian* pw = partial + (size_t)w * (p.lb + 1);
-    at[p.c * w].push_back(&pw[p.lb]);
-    for (uint32_t k = 0; k < p.lb; ++k) at[p.c * w + k].push_back(&pw[k]);
-  }
   // 4 x 64-bit host arithmetic (host_fq64.h): this pass is the whole CPU tail of an MSM
   h64::Jac acc = h64::identity();
   for (int pos = (int)top; pos >= 0; --pos) {
     acc = h64::jdouble(acc);
-    for (const Jacobian* t : at[pos]) acc = h64::jadd(acc, h64::load(*t));
+    // the terms at this bit: partial[w][k] with c w + k = pos and k < lb, and the window total partial[w][lb] at k = 0.
+    // Production plans have lb = c - 1 (one window per position); tiny windows keep lb >= kSegLog > c - 1, where the
+    // upper bit sums of window w share positions with window w + 1
+    for (uint32_t w = std::min((uint32_t)pos / p.c, p.W - 1);; --w) {
+      const uint32_t k = (uint32_t)pos - p.c * w;
+      if (k > p.lb) break;
+      const Jacobian* pw = partial + (size_t)w * (p.lb + 1);
+      if (k == 0) acc = h64::jadd(acc, h64::load(pw[p.lb]));
+      if (k < p.lb) acc = h64::jadd(acc, h64::load(pw[k]));
+      if (w == 0) break;
+    }
   }
   return h64::store(acc);
 }
