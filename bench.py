@@ -31,10 +31,11 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--prewarm-seconds", type=float, default=0.5,
-                    help="untimed load on the device BEFORE the --warmup steps, so that a short run (the driver's "
-                         "--steps 20) does not time the GPU's clock ramp: 0.5 s of the same steps; 0 disables. "
-                         "Reported as device_prewarm_s.  profiles/r03_bench_warmup_sensitivity.txt")
+    ap.add_argument("--prewarm-steps", type=int, default=64,
+                    help="untimed steps run BEFORE the --warmup steps (same pipelined loop, same count on every rank: "
+                         "the steps contain the gather collective), so that a short run -- the driver's --steps 20 -- "
+                         "does not time the GPU's clock ramp; 0 disables.  Reported as device_prewarm_steps.  "
+                         "profiles/r03_bench_warmup_sensitivity.txt")
     ap.add_argument("--log-size", type=int, default=20)
     ap.add_argument("--instances", type=int, default=5, help="instances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -192,10 +193,8 @@ def main(argv=None):
         red_ms.append(t.reduce_ms)
         fin_ms.append(t.final_ms)
 
-    if args.prewarm_seconds > 0:                         # clocks up before anything is counted (not a warm-up STEP:
-        t_end = time.perf_counter() + args.prewarm_seconds   # the W steps below are still run, the K steps still timed alone)
-        while time.perf_counter() < t_end:
-            run_steps(16, lambda t: None)              # (pipelined like the timed loop: the device stays busy)
+    if args.prewarm_steps > 0:                           # clocks up before anything is counted (not warm-up STEPS: the W
+        run_steps(args.prewarm_steps, lambda t: None)    # steps below are still run, the K steps still timed alone)
     outs = run_steps(args.warmup, lambda t: None)
     barrier()
     t0 = time.perf_counter()
@@ -329,7 +328,7 @@ def main(argv=None):
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "device_prewarm_s": args.prewarm_seconds,   # untimed load before the warm-up steps (GPU clock ramp), see --help
+            "device_prewarm_steps": args.prewarm_steps,   # untimed load before the warm-up steps (GPU clock ramp), see --help
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",

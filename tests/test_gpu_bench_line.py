@@ -38,7 +38,7 @@ def test_bench_prints_one_contract_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["bit_exact_vs_gpu"] is True
     assert x["drop_in_caller"]["single_call_ms"]["resident_2^18"] < 5.0
     # round 3: where the inputs live, build-derived instruction counts, the bases-cache figures beside the cache-off ones
-    assert "device-resident" in x["config"]["inputs"] and x["device_prewarm_s"] == 0.5
+    assert "device-resident" in x["config"]["inputs"] and x["device_prewarm_steps"] == 64
     sec = r["secondary"]
     assert 1500 <= sec["multiplier_instructions_per_mixed_addition"] <= 1600 and "isa_counts.json" in sec["counts_source"]
     assert 0.3 < sec["frac"] < 0.9
