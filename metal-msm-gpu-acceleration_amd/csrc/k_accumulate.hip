@@ -17,14 +17,20 @@ namespace msm_amd {
 // alone): with several streams in flight this leaves register file and wave slots for the sort / reduce
 // kernels of the neighbouring instance, which otherwise cannot be placed until the whole accumulate grid has
 // drained (measured: a 1024-thread plan_kernel workgroup waited 1.4 ms behind 3-wave accumulate waves).
-template <bool LOW_OCC>
-__global__ void __launch_bounds__(64)
-accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                  const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
-                  const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
-                  const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
-                  uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
-  if (LOW_OCC) asm volatile("v_mov_b32 v175, 0" ::: "v175");   // 176 allocated: 2 waves/SIMD, 160 VGPRs left free
+// PREFETCH: gather the packed record of point i + 1 while point i is added (16 more live registers).
+// PIN: touch v175 so that the kernel allocates 176 VGPRs and runs at two waves per SIMD whatever it needs itself.
+template <bool PREFETCH, bool PIN, int WHATIF = 0>
+__device__ __forceinline__ void
+accumulate_body(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
+                const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
+                const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
+                uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
+  constexpr bool LOW_OCC = PREFETCH;
+  // WHATIF (timing experiments, -DMSM_AMD_EXPERIMENTS builds only): 1 = gathers without arithmetic, 2 = arithmetic
+  // on a 1 MB slice of the bases (every gather hits the L2)
+  constexpr uint32_t IDX_MASK = WHATIF == 2 ? 0x3FFFu : 0x7FFFFFFFu;
+  if (PIN) asm volatile("v_mov_b32 v175, 0" ::: "v175");
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= counters->total_items) return;
   const uint2 it = order[slot];
@@ -49,8 +55,8 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
   uint32_t next_idx = cnt > 1 ? idx[1] : 0u;
   AffPacked pre;
   if (LOW_OCC) {
-    pre.x = load_u256(&bases[cur_idx & 0x7FFFFFFFu].x);
-    pre.y = load_u256(&bases[cur_idx & 0x7FFFFFFFu].y);
+    pre.x = load_u256(&bases[cur_idx & IDX_MASK].x);
+    pre.y = load_u256(&bases[cur_idx & IDX_MASK].y);
   }
 #pragma unroll 1
   for (uint32_t i = 0; i < cnt; ++i) {
@@ -58,16 +64,24 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
     if (LOW_OCC) {
       rec = pre;
       if (i + 1 < cnt) {
-        pre.x = load_u256(&bases[next_idx & 0x7FFFFFFFu].x);
-        pre.y = load_u256(&bases[next_idx & 0x7FFFFFFFu].y);
+        pre.x = load_u256(&bases[next_idx & IDX_MASK].x);
+        pre.y = load_u256(&bases[next_idx & IDX_MASK].y);
       }
     } else {
-      rec.x = load_u256(&bases[cur_idx & 0x7FFFFFFFu].x);
-      rec.y = load_u256(&bases[cur_idx & 0x7FFFFFFFu].y);
+      rec.x = load_u256(&bases[cur_idx & IDX_MASK].x);
+      rec.y = load_u256(&bases[cur_idx & IDX_MASK].y);
     }
     const bool negate = (cur_idx >> 31) != 0;   // negative digit: add -P (signed digits, see digits_kernel)
     cur_idx = next_idx;
     if (i + 2 < cnt) next_idx = idx[i + 2];
+    if (WHATIF == 1) {
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        acc.x.l[l] ^= rec.x.v[l];
+        acc.y.l[l] ^= rec.y.v[l];
+      }
+      continue;
+    }
     if (affpacked_is_identity(rec)) continue;   // an identity base adds nothing (one word tells: affi_pack)
     AffI cur = affi_unpack_finite(rec);
     {
@@ -97,6 +111,109 @@ accumulate_kernel(const AffPacked* __restrict__ bases, const uint32_t* __restric
   if (size <= CH) {
     store_pti(&buckets[b], acc);
   } else {
+    store_pti(&partials[(size_t)win_base[w] + item_start[b] + j], acc);
+  }
+}
+
+#define MSM_ACC_PARAMS const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,                       \
+                       const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,           \
+                       const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,                \
+                       const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,        \
+                       uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials
+#define MSM_ACC_FWD bases, sorted, bucket_start, bucket_size, item_start, win_base, order, counters, n, lb, CH, buckets, partials
+// accumulate_kernel<true>: two waves per SIMD (pinned), prefetch.  accumulate_kernel<false>: the same body without
+// prefetch and pin (a build for A/B runs; it needs 173 VGPRs, so it is a two-wave kernel too).
+template <bool LOW_OCC>
+__global__ void __launch_bounds__(64) accumulate_kernel(MSM_ACC_PARAMS) {
+  accumulate_body<LOW_OCC, LOW_OCC>(MSM_ACC_FWD);
+}
+#if defined(MSM_AMD_EXPERIMENTS)
+__global__ void __launch_bounds__(64) accumulate_whatif_gathers(MSM_ACC_PARAMS) { accumulate_body<true, true, 1>(MSM_ACC_FWD); }
+__global__ void __launch_bounds__(64) accumulate_whatif_math(MSM_ACC_PARAMS) { accumulate_body<true, true, 2>(MSM_ACC_FWD); }
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) accumulate_whatif_math_w3(MSM_ACC_PARAMS) {
+  accumulate_body<false, false, 2>(MSM_ACC_FWD);
+}
+#endif
+// Three waves per SIMD: the compiler is held to 168 VGPRs (8 of them spilled outside the loop), no prefetch.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) accumulate_kernel_w3(MSM_ACC_PARAMS) {
+  accumulate_body<false, false>(MSM_ACC_FWD);
+}
+
+// The register-lean build of the same kernel: at most 128 VGPRs, so FOUR waves share a SIMD (the multiplier pipe
+// issues one v_mad_u64_u32 every 5.3 cycles with four waves resident against 6.1 with two, and a simple instruction
+// next to it 4.5 against 5.9: tools/microbench/valu_mix.hip).  Same work items, same results bit for bit.  No
+// software prefetch of the next base: with four waves per SIMD the other three cover the gather.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+accumulate_kernel_lean(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                       const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
+                       const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
+                       const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
+                       uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= counters->total_items) return;
+  const uint2 it = order[slot];
+  const uint32_t b = it.x, j = it.y;
+  const uint32_t size = bucket_size[b];
+  const uint32_t cnt = min(size - j * CH, CH);
+  const uint32_t* idx = sorted + (size_t)(b >> lb) * n + bucket_start[b] + j * CH;
+  PtI acc = pti_identity();
+  enum : uint32_t { kEmpty = 0, kOne = 1, kMany = 2 };
+  uint32_t state = kEmpty;
+  uint32_t next_idx = idx[0];
+  AffPacked pre;
+  pre.x = load_u256(&bases[next_idx & 0x7FFFFFFFu].x);
+  pre.y = load_u256(&bases[next_idx & 0x7FFFFFFFu].y);
+#pragma unroll 1
+  for (uint32_t i = 0; i < cnt; ++i) {
+    const uint32_t cur_idx = next_idx;
+    const AffPacked rec = pre;
+    if (i + 1 < cnt) next_idx = idx[i + 1];
+    // the gather of the next base is issued in the middle of the addition, when the registers are there
+    const auto fetch_next = [&]() {
+      if (i + 1 < cnt) {
+        pre.x = load_u256(&bases[next_idx & 0x7FFFFFFFu].x);
+        pre.y = load_u256(&bases[next_idx & 0x7FFFFFFFu].y);
+      }
+    };
+    const auto unpack = [](const AffPacked& r, uint32_t tagged) {
+      AffI c = affi_unpack_finite(r);
+      const bool negate = (tagged >> 31) != 0;
+      const fe29 ny = Fq29::neg_wide(c.y);
+#pragma unroll
+      for (int l = 0; l < 9; ++l) c.y.l[l] = negate ? ny.l[l] : c.y.l[l];
+      return c;
+    };
+    const auto again = [&]() {
+      AffPacked r;
+      r.x = load_u256(&bases[cur_idx & 0x7FFFFFFFu].x);
+      r.y = load_u256(&bases[cur_idx & 0x7FFFFFFFu].y);
+      return unpack(r, cur_idx);
+    };
+    if (affpacked_is_identity(rec)) {
+      fetch_next();
+      continue;
+    }
+    const AffI cur = unpack(rec, cur_idx);
+    MSM_SCHED_FENCE();
+    if (state == kMany) {
+      MSM_ISA_MARK("begin mixed_addition");
+      if (!pti_madd_lean(acc, cur, again, fetch_next)) state = kEmpty;
+      MSM_ISA_MARK("end");
+    } else if (state == kOne) {
+      MSM_ISA_MARK("begin affine_start");
+      state = pti_mmadd_lean(acc, cur, again, fetch_next) ? (uint32_t)kMany : (uint32_t)kEmpty;
+      MSM_ISA_MARK("end");
+    } else {
+      acc = pti_from_affi(cur);
+      state = kOne;
+      fetch_next();
+    }
+  }
+  if (state == kEmpty) acc = pti_identity();
+  if (size <= CH) {
+    store_pti(&buckets[b], acc);
+  } else {
+    const uint32_t w = b >> lb;
     store_pti(&partials[(size_t)win_base[w] + item_start[b] + j], acc);
   }
 }
@@ -162,20 +279,34 @@ combine_big_kernel(const uint32_t* __restrict__ big_list, const PlanCounters* __
   }
 }
 
+// variant: 0 = three waves per SIMD (no prefetch), 1 = two waves per SIMD (register pin, prefetch), 2 = register-lean
+// (four waves per SIMD).  lds_bytes > 0 caps the resident workgroups per CU through the LDS allocation (160 KiB per
+// CU: 13 KiB per 64-lane workgroup = 12 waves per CU = 3 per SIMD), leaving register file for the other streams.
 void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
-                       PtI* partials, bool low_occupancy, hipEvent_t before_kernel, hipEvent_t after_kernel) {
+                       PtI* partials, int variant, uint32_t lds_bytes, hipEvent_t before_kernel, hipEvent_t after_kernel) {
   if (before_kernel) (void)hipEventRecord(before_kernel, st);
-  if (low_occupancy) {
-    hipLaunchKernelGGL(accumulate_kernel<true>, dim3((unsigned)((p.max_items + 63) / 64)), dim3(64), 0, st, bases,
-                       (const uint32_t*)b.sorted, (const uint32_t*)b.bucket_start, (const uint32_t*)b.bucket_size,
-                       (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, (const uint2*)b.order,
-                       (const PlanCounters*)b.counters, p.n, p.lb, p.CH, buckets, partials);
+  const dim3 grid((unsigned)((p.max_items + 63) / 64)), block(64);
+#define MSM_ACC_ARGS bases, (const uint32_t*)b.sorted, (const uint32_t*)b.bucket_start, (const uint32_t*)b.bucket_size, \
+                     (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, (const uint2*)b.order,                \
+                     (const PlanCounters*)b.counters, p.n, p.lb, p.CH, buckets, partials
+  if (variant == 2) {
+    hipLaunchKernelGGL(accumulate_kernel_lean, grid, block, lds_bytes, st, MSM_ACC_ARGS);
+  } else if (variant == 3) {
+    hipLaunchKernelGGL(accumulate_kernel_w3, grid, block, lds_bytes, st, MSM_ACC_ARGS);
+#if defined(MSM_AMD_EXPERIMENTS)
+  } else if (variant == 10) {
+    hipLaunchKernelGGL(accumulate_whatif_gathers, grid, block, lds_bytes, st, MSM_ACC_ARGS);
+  } else if (variant == 11) {
+    hipLaunchKernelGGL(accumulate_whatif_math, grid, block, lds_bytes, st, MSM_ACC_ARGS);
+  } else if (variant == 12) {
+    hipLaunchKernelGGL(accumulate_whatif_math_w3, grid, block, lds_bytes, st, MSM_ACC_ARGS);
+#endif
+  } else if (variant == 1) {
+    hipLaunchKernelGGL(accumulate_kernel<true>, grid, block, lds_bytes, st, MSM_ACC_ARGS);
   } else {
-    hipLaunchKernelGGL(accumulate_kernel<false>, dim3((unsigned)((p.max_items + 63) / 64)), dim3(64), 0, st, bases,
-                       (const uint32_t*)b.sorted, (const uint32_t*)b.bucket_start, (const uint32_t*)b.bucket_size,
-                       (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, (const uint2*)b.order,
-                       (const PlanCounters*)b.counters, p.n, p.lb, p.CH, buckets, partials);
+    hipLaunchKernelGGL(accumulate_kernel<false>, grid, block, lds_bytes, st, MSM_ACC_ARGS);
   }
+#undef MSM_ACC_ARGS
   if (after_kernel) (void)hipEventRecord(after_kernel, st);
 }
 

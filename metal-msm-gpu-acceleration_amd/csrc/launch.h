@@ -71,7 +71,7 @@ void launch_ark_affine_to_affine(hipStream_t st, const uint8_t* in, uint32_t n, 
 
 // k_accumulate.hip
 void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
-                       PtI* partials, bool low_occupancy, hipEvent_t before_kernel, hipEvent_t after_kernel);
+                       PtI* partials, int variant, uint32_t lds_bytes, hipEvent_t before_kernel, hipEvent_t after_kernel);
 
 void launch_combine(hipStream_t st, const Plan& p, const SortBuffers& b, PtI* buckets, PtI* partials);
 

@@ -170,7 +170,8 @@ struct msm_amd_ctx {
                                          // queues HIP gives a process -- main, front, two reduce -- share a queue
                                          // with the accumulate grid and wait behind it: measured, 1.6x slower.)
   bool alt_reduce = true;                // MSM_AMD_ALT_REDUCE=0: one reduce stream
-  bool low_occ_accumulate = true;        // 2-wave accumulate variant (set from overlap_front; MSM_AMD_LOW_OCC overrides)
+  int acc_variant = 1;                   // accumulate kernel build (launch_accumulate): 0 three waves/SIMD, 1 two, 2 register-lean
+  uint32_t acc_lds = 0;                  // LDS bytes per accumulate workgroup: caps its waves per CU (MSM_AMD_ACC_LDS)
   uint32_t seq = 0;
   hipStream_t front_stream = nullptr;    // side stream: conversion, digits, sort, work-item planning
   hipStream_t copy_stream = nullptr;     // host-buffer entry points: uploads (DMA when the caller registered its buffers)
@@ -814,7 +815,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
     w.reduce_pending = false;
   }
   launch_accumulate(st, p, bases, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p,
-                    ctx->low_occ_accumulate, slot.ev[EV_ACC_K0], slot.ev[EV_ACC_K1]);
+                    ctx->acc_variant, ctx->acc_lds, slot.ev[EV_ACC_K0], slot.ev[EV_ACC_K1]);
   HIP_TRY(ctx, hipEventRecord(w.acc_done, st));
   w.acc_pending = true;
 
@@ -1610,8 +1611,10 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
   if (const char* e = std::getenv("MSM_AMD_OVERLAP_FRONT")) ctx->overlap_front = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSM_AMD_ALT_REDUCE")) ctx->alt_reduce = std::atoi(e) != 0;
   if (const char* e = std::getenv("MSM_AMD_LONE_SINGLE_STREAM")) ctx->lone_single_stream = std::atoi(e) != 0;
-  ctx->low_occ_accumulate = ctx->overlap_front;
-  if (const char* e = std::getenv("MSM_AMD_LOW_OCC")) ctx->low_occ_accumulate = std::atoi(e) != 0;
+  ctx->acc_variant = ctx->overlap_front ? 1 : 0;
+  if (const char* e = std::getenv("MSM_AMD_LOW_OCC")) ctx->acc_variant = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("MSM_AMD_ACC_VARIANT")) ctx->acc_variant = std::atoi(e);
+  if (const char* e = std::getenv("MSM_AMD_ACC_LDS")) ctx->acc_lds = (uint32_t)std::atoi(e);
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   // the short front-end / reduction kernels get priority over the long accumulate grid
