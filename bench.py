@@ -122,12 +122,29 @@ def main(argv=None):
     gpu_index = local_rank % visible if shared else local_rank
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
-    if args.backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" IS RCCL on ROCm
-        coll_dev = dev
-    else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        coll_dev = torch.device("cpu")
+    t_init = time.perf_counter()
+    try:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" IS RCCL on ROCm
+            coll_dev = dev
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            coll_dev = torch.device("cpu")
+        # first contact between the ranks: one tiny all-reduce before anything else is built on the communicator
+        probe = torch.ones(1, device=coll_dev)
+        dist.all_reduce(probe)
+        if int(probe.item()) != world:
+            raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+    except Exception as e:   # noqa: BLE001 -- the text is what the operator of a new multi-GPU host needs
+        print(f"bench.py: rank {rank}/{world}: communicator setup failed ({args.backend}, "
+              f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '<unset>')}, "
+              f"MASTER_ADDR={os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}): "
+              f"{type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    comm_init_s = time.perf_counter() - t_init
+    started_file = os.environ.get("MSM_AMD_RANK_STARTED_FILE")
+    if started_file:                                   # tells multi_gpu.launch_local_ranks that this rank's group works
+        open(started_file, "w").close()
 
     m = importlib.import_module(PKG)
     cfg = m.setup_metal_state(gpu_index)           # fails loudly without a gfx950 device
@@ -336,6 +353,8 @@ def main(argv=None):
             "dtype": "u32x8 (256-bit Montgomery integer)",
             "data": "synthetic",
             "rccl_ranks_seen": ranks_seen,
+            "rccl_init_s": round(comm_init_s, 3),
+            "ipc_mode_legacy_env": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "<unset>"),
             "ranks_pinned_to_gpu_numa_node": bool(numa_pinned),
             "collective": "rccl" if args.backend == "nccl" else "gloo (rehearsal, not RCCL)",
             "parity": ("bit-exact vs the CPU oracle on every rank's own instances" if not args.no_cpu_baseline

@@ -163,6 +163,13 @@ int msm_amd_host_unregister(msm_amd_ctx* ctx, const void* ptr);
  * stats: [0] hits, [1] misses (entries filled), [2] invalidations (checksum mismatch), [3] bytes held, [4] entries. */
 int msm_amd_set_bases_cache(msm_amd_ctx* ctx, size_t max_bytes);
 int msm_amd_bases_cache_stats(msm_amd_ctx* ctx, uint64_t stats[5]);
+/* A caller that DOES change bases in place says so: the entries of the array at host_points (NULL: all entries) are
+ * dropped, the next call uploads again.  This is the contract's other half; the sampling above is only a net. */
+int msm_amd_bases_cache_invalidate(msm_amd_ctx* ctx, const void* host_points);
+/* full != 0 (or MSM_AMD_BASES_CACHE_VERIFY=full at msm_amd_init): every hit re-hashes EVERY record of the caller's
+ * array (64 contiguous slices on four host threads, ~1.5 ms per 2^20 points) before the cached copy is used -- no
+ * stale window at all, at about the cost of the upload the cache saves (the conversion is still saved).  0: sampling. */
+int msm_amd_set_bases_cache_verify(msm_amd_ctx* ctx, int full);
 
 /* ---- hybrid front-end ----------------------------------------------------------------------- */
 /* msm_best::<G1Affine, ..>(scalars, points) -> G1 (msm.rs:424-445): filter_zeros (drop zero scalars when at
@@ -219,7 +226,14 @@ int msm_amd_wait_batch(msm_amd_ctx* ctx, int ticket);
  * The work stays in flight: a ticket of msm_amd_submit_batch_device stays valid and may be waited for again; after a
  * blocking entry point timed out, the next call first checks whether the device has caught up (and fails the same
  * way if not); msm_amd_synchronize waits once more; msm_amd_destroy gives the device resources up rather than
- * freeing memory under running kernels. */
+ * freeing memory under running kernels.
+ * The same bound covers memory management: the library never calls hipMalloc / hipHostMalloc / hipFree / hipHostFree
+ * while the ctx has work in flight (they may wait for the device, hipFree always does).  A call that has to GROW a
+ * workspace, a page-locked result slot or the staging ring first waits -- bounded -- for the ctx's streams to run
+ * empty and returns MSM_AMD_PIPELINE_ERROR ("device busy ... cannot grow") if they do not; buffers that are outgrown
+ * or dropped (bases cache entries, msm_amd_device_free on a busy ctx) are released when the ctx is idle again.
+ * After a timeout, host buffers the caller registered with msm_amd_host_register may still be read by DMA: keep
+ * them alive until msm_amd_synchronize has returned MSM_AMD_OK. */
 int msm_amd_set_wait_timeout_ms(msm_amd_ctx* ctx, uint32_t timeout_ms);
 
 /* ---- several GPUs ---------------------------------------------------------
@@ -234,6 +248,16 @@ int msm_amd_msm_batch_multi(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_l
 int msm_amd_msm_batch_multi_device(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout,
                                    size_t n_inst, const void* const* d_scalars, const void* const* d_points,
                                    const size_t* n, void* out_host);
+/* Pipelined form of msm_amd_msm_batch_multi_device (the multi-ctx twin of msm_amd_submit_batch_device /
+ * msm_amd_wait_batch): submit enqueues every ctx's share and returns a ticket, wait finishes all shares and writes
+ * out_host + 96 j (out_host must stay valid until then).  Up to 4 batches may be in flight per ctx, so a caller
+ * looping over batches -- benches/msm_benchmark.rs:29-34 -- keeps every GPU busy across calls.  wait frees the ticket
+ * on success; after a bounded-wait timeout (MSM_AMD_PIPELINE_ERROR, work still in flight) the ticket stays valid. */
+typedef struct msm_amd_multi_ticket msm_amd_multi_ticket;
+int msm_amd_submit_batch_multi_device(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout,
+                                      size_t n_inst, const void* const* d_scalars, const void* const* d_points,
+                                      const size_t* n, void* out_host, msm_amd_multi_ticket** ticket);
+int msm_amd_wait_batch_multi(msm_amd_multi_ticket* ticket);
 /* ONE instance of n points over several ctxs, split by point range ("single huge instance"):
  * ctx g uploads and runs the MSM of points [begin_g, end_g) (msm_amd_shard_range), the partial results are added with
  * msm_amd_sum_points -- the algebra of the reference's GPU + CPU split, src/metal/msm.rs:385-419.  Host buffers in a

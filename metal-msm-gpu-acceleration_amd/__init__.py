@@ -51,6 +51,8 @@ EXPORTS = [
     "msm_amd_tables_info", "msm_amd_tables_free", "msm_amd_msm_tables",
     "msm_amd_set_wait_timeout_ms", "msm_amd_set_bases_cache", "msm_amd_bases_cache_stats", "msm_amd_test_hold",
     "msm_amd_test_release", "msm_amd_msm_batch_multi", "msm_amd_msm_batch_multi_device", "msm_amd_msm_range_multi", "msm_amd_shard_range",
+    "msm_amd_submit_batch_multi_device", "msm_amd_wait_batch_multi", "msm_amd_bases_cache_invalidate",
+    "msm_amd_set_bases_cache_verify",
     "msm_amd_scalar_bytes", "msm_amd_point_bytes", "msm_amd_shard_owner",
     "msm_amd_shard_count", "msm_amd_ctx_device", "msm_amd_pin_thread_to_device", "msm_amd_gather_init",
     "msm_amd_gather_size", "msm_amd_gather_all", "msm_amd_gather_last_error", "msm_amd_gather_destroy",
@@ -167,11 +169,15 @@ def _lib():
         L.msm_amd_set_wait_timeout_ms.argtypes = [c_void_p, c_uint32]
         L.msm_amd_set_bases_cache.argtypes = [c_void_p, c_size_t]
         L.msm_amd_bases_cache_stats.argtypes = [c_void_p, POINTER(c_uint64)]
+        L.msm_amd_bases_cache_invalidate.argtypes = [c_void_p, c_void_p]
+        L.msm_amd_set_bases_cache_verify.argtypes = [c_void_p, c_int]
         L.msm_amd_test_hold.argtypes = [c_void_p, c_uint32, POINTER(c_void_p)]
         L.msm_amd_test_release.argtypes = [c_void_p, c_void_p]
         L.msm_amd_msm_batch_multi.argtypes = [POINTER(c_void_p), c_size_t, c_int, c_int, c_size_t, POINTER(c_void_p),
                                               POINTER(c_void_p), POINTER(c_size_t), c_void_p]
         L.msm_amd_msm_batch_multi_device.argtypes = L.msm_amd_msm_batch_multi.argtypes
+        L.msm_amd_submit_batch_multi_device.argtypes = L.msm_amd_msm_batch_multi.argtypes + [POINTER(c_void_p)]
+        L.msm_amd_wait_batch_multi.argtypes = [c_void_p]
         L.msm_amd_msm_range_multi.argtypes = [POINTER(c_void_p), c_size_t, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                               c_void_p]
         L.msm_amd_shard_range.argtypes = [c_size_t, c_size_t, c_size_t, POINTER(c_size_t), POINTER(c_size_t)]
@@ -298,6 +304,15 @@ class MsmConfig:
     def set_bases_cache(self, max_bytes: int):
         """Opt-in cache of converted bases for the host-slice entry points (0 = off)."""
         self._check(_lib().msm_amd_set_bases_cache(self.h, max_bytes))
+
+    def bases_cache_invalidate(self, data=None):
+        """The caller's word that the points array `data` (a bytes object handed over earlier; None: every array)
+        changed in place: its cache entries are dropped."""
+        ptr = None if data is None else ctypes.cast(ctypes.c_char_p(data), c_void_p)
+        self._check(_lib().msm_amd_bases_cache_invalidate(self.h, ptr))
+
+    def set_bases_cache_verify(self, full: bool):
+        self._check(_lib().msm_amd_set_bases_cache_verify(self.h, 1 if full else 0))
 
     def bases_cache_stats(self):
         st = (c_uint64 * 5)()
@@ -462,6 +477,32 @@ def msm_batch_multi(configs, scalars_list, points_list, ns, scalar_layout=SCALAR
     if st != OK:
         detail = "; ".join(_lib().msm_amd_last_error(c.h).decode() for c in configs)
         raise MsmError(st, detail)
+    return [out.raw[96 * i:96 * i + 96] for i in range(k)]
+
+
+def submit_batch_multi_device(configs, d_scalars, d_points, ns, scalar_layout=SCALAR_MONT_LE,
+                              point_layout=POINT_H2C_AFFINE):
+    """Pipelined form of msm_batch_multi(..., device=True): enqueue every config's share, return a handle for
+    wait_batch_multi (msm_amd_submit_batch_multi_device)."""
+    k, g = len(ns), len(configs)
+    cc = (c_void_p * g)(*[c.h for c in configs])
+    sp = (c_void_p * k)(*d_scalars)
+    pp = (c_void_p * k)(*d_points)
+    nn = (c_size_t * k)(*ns)
+    out = ctypes.create_string_buffer(96 * k)
+    ticket = c_void_p()
+    st = _lib().msm_amd_submit_batch_multi_device(cc, g, scalar_layout, point_layout, k, sp, pp, nn, out,
+                                                  ctypes.byref(ticket))
+    if st != OK:
+        raise MsmError(st, "; ".join(_lib().msm_amd_last_error(c.h).decode() for c in configs))
+    return (ticket, out, k, configs)
+
+
+def wait_batch_multi(handle):
+    ticket, out, k, configs = handle
+    st = _lib().msm_amd_wait_batch_multi(ticket)
+    if st != OK:
+        raise MsmError(st, "; ".join(_lib().msm_amd_last_error(c.h).decode() for c in configs))
     return [out.raw[96 * i:96 * i + 96] for i in range(k)]
 
 

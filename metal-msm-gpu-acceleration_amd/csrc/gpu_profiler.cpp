@@ -298,6 +298,8 @@ int main(int argc, char** argv) {
                  n - split_at, threads,
                  reference_split ? "the reference's policy, msm.rs:377-383" : "measured on MI355X; --reference-split for the reference's policy");
 
+  std::vector<uint8_t> out_odd(out.size());
+  msm_amd_multi_ticket* pending = nullptr;
   auto t0 = std::chrono::steady_clock::now();
   for (unsigned r = 0; r < retries + warmup; ++r) {
     if (r == warmup) t0 = std::chrono::steady_clock::now();
@@ -315,10 +317,24 @@ int main(int argc, char** argv) {
         sp[j] = host_inputs ? (const void*)h_sc[j].data() : d_sc[j];
         pp[j] = host_inputs ? (const void*)h_pts[j].data() : d_pts[j];
       }
-      st = host_inputs ? msm_amd_msm_batch_multi(g_ctxs.data(), G, sc_layout, pt_layout, num_instances, sp.data(), pp.data(),
-                                                 ns.data(), out.data())
-                       : msm_amd_msm_batch_multi_device(g_ctxs.data(), G, sc_layout, pt_layout, num_instances, sp.data(),
-                                                        pp.data(), ns.data(), out.data());
+      if (host_inputs) {
+        st = msm_amd_msm_batch_multi(g_ctxs.data(), G, sc_layout, pt_layout, num_instances, sp.data(), pp.data(), ns.data(),
+                                     out.data());
+      } else {
+        // resident inputs: retry r + 1 is submitted before retry r is waited for, so that every GPU's pipeline stays
+        // full across the retries (msm_amd_submit_batch_multi_device); the last retry's results end up in `out`
+        std::vector<uint8_t>& dst = r % 2 ? out_odd : out;
+        msm_amd_multi_ticket* t = nullptr;
+        st = msm_amd_submit_batch_multi_device(g_ctxs.data(), G, sc_layout, pt_layout, num_instances, sp.data(), pp.data(),
+                                               ns.data(), dst.data(), &t);
+        if (!st && pending) st = msm_amd_wait_batch_multi(pending);
+        pending = t;
+        if (!st && r + 1 == retries + warmup) {
+          st = msm_amd_wait_batch_multi(pending);
+          pending = nullptr;
+          if (!st && r % 2) out = out_odd;
+        }
+      }
       if (st) {
         for (msm_amd_ctx* c : g_ctxs)
           if (*msm_amd_last_error(c)) std::fprintf(stderr, "[ERROR] device %d: %s\n", msm_amd_ctx_device(c), msm_amd_last_error(c));

@@ -86,8 +86,10 @@ struct BasesCacheEntry {
   size_t n = 0;
   int layout = 0;
   std::vector<uint64_t> phase_hash;
+  std::vector<uint64_t> chunk_hash;   // kCacheChunks contiguous slices: the FULL verification (bases_cache_verify)
   void* d_prepared = nullptr;   // n x AffPacked
   uint64_t last_use = 0;        // bases_cache_call of the last call that used it
+  uint64_t wanted_by = 0;       // bases_cache_call of the last call whose arguments name it (bases_cache_reserve)
   uint32_t next_phase = 1;
 };
 
@@ -206,7 +208,19 @@ struct msm_amd_ctx {
   // Opt-in cache of converted bases for the host-slice entry points (msm_amd_set_bases_cache, MSM_AMD_BASES_CACHE_MB)
   std::vector<BasesCacheEntry> bases_cache;
   size_t bases_cache_budget = 0, bases_cache_bytes = 0;
+  // 0 = sampled verification of a hit (phase 0 + one rotating phase of the caller's records), 1 = every record
+  // re-hashed on every hit (msm_amd_set_bases_cache_verify, MSM_AMD_BASES_CACHE_VERIFY=full)
+  int bases_cache_verify = 0;
   uint64_t bases_cache_call = 0, bases_cache_hits = 0, bases_cache_misses = 0, bases_cache_invalidations = 0;
+  // device room for cache entries, allocated at the START of a host-slice call while the ctx is idle (nothing is ever
+  // allocated under work in flight) and taken by bases_cache_insert when the instance is dispatched
+  struct CacheReserve {
+    const void* host;
+    size_t n;
+    int layout;
+    void* d;
+  };
+  std::vector<CacheReserve> cache_reserve;
   AffPacked* convert_into = nullptr;   // enqueue_msm writes the converted bases of the next instance here (a cache fill)
   // Device buffers replaced by bigger ones while work was in flight.  hipFree synchronises the whole device: inside
   // a submit it would stall the pipeline and, on a device that does not answer, block without bound.  They are
@@ -264,6 +278,11 @@ bool drain_streams_bounded(msm_amd_ctx* ctx) {
   }
   return true;
 }
+
+// Error paths and set-up steps: the bounded drain; a device that does not get there leaves the ctx marked stalled (the
+// next entry point checks whether it has caught up) instead of holding the caller.
+bool drain_or_mark_stalled(msm_amd_ctx* ctx);
+int sync_stream_bounded(msm_amd_ctx* ctx, hipStream_t st, const char* what);
 
 // hipEventSynchronize may park the thread (it did, for more than a millisecond, inside a process that also hosts
 // torch's thread pools) and it waits without bound: a device that stalls would block the caller of a blocking MSM
@@ -331,8 +350,50 @@ void reap_graveyard(msm_amd_ctx* ctx) {
   ctx->graveyard.clear();
 }
 
+// hipMalloc / hipHostMalloc / hipFree / hipHostFree may wait for the device (hipFree always does).  With work in flight
+// on a device that does not answer they would block without bound, before any bounded wait is reached -- so nothing
+// is allocated or released while the ctx has work in flight: a buffer that must grow first waits, WITH the ctx's wait
+// bound, for the ctx's streams to run empty, and the call fails with MSM_AMD_PIPELINE_ERROR if they do not.  (On a
+// healthy device this costs a pipeline drain on the first use of a workspace, never in steady state.)
+int quiesce_for_allocation(msm_amd_ctx* ctx, const char* what) {
+  if (streams_idle(ctx)) return MSM_AMD_OK;
+  if (drain_streams_bounded(ctx)) return MSM_AMD_OK;
+  ctx->stalled = true;
+  return fail(ctx, MSM_AMD_PIPELINE_ERROR,
+              std::string("device busy past the wait bound of ") + std::to_string(ctx->wait_timeout_ms) +
+                  " ms: cannot grow " + what + " while earlier work is in flight (msm_amd_synchronize waits again)");
+}
+
+// hipStreamSynchronize with the ctx's wait bound (the stream is polled): PIPELINE_ERROR, ctx marked stalled, when the
+// device does not get there.
+int sync_stream_bounded(msm_amd_ctx* ctx, hipStream_t st, const char* what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return MSM_AMD_OK;
+    (void)hipGetLastError();
+    if (q != hipErrorNotReady)
+      return fail(ctx, MSM_AMD_PIPELINE_ERROR, std::string("hipStreamQuery (") + what + "): " + hipGetErrorString(q));
+    const auto waited = std::chrono::steady_clock::now() - t0;
+    if (ctx->wait_timeout_ms && waited > std::chrono::milliseconds(ctx->wait_timeout_ms)) {
+      ctx->stalled = true;
+      return fail(ctx, MSM_AMD_PIPELINE_ERROR, "timed out after " + std::to_string(ctx->wait_timeout_ms) +
+                                                   " ms waiting for the stream (" + what + ")");
+    }
+    if (waited > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    else __builtin_ia32_pause();
+  }
+}
+
+bool drain_or_mark_stalled(msm_amd_ctx* ctx) {
+  if (drain_streams_bounded(ctx)) return true;
+  ctx->stalled = true;
+  return false;
+}
+
 int ensure(msm_amd_ctx* ctx, DeviceBuf& b, size_t bytes) {
   if (bytes <= b.cap) return MSM_AMD_OK;
+  if (int rc = quiesce_for_allocation(ctx, "a device workspace")) return rc;
   if (b.p) ctx->graveyard.push_back(b.p);   // freed later, see msm_amd_ctx::graveyard
   b.p = nullptr;
   b.cap = 0;
@@ -568,6 +629,7 @@ int slot_prepare(msm_amd_ctx* ctx, InstanceSlot& s, size_t partial_count) {
     s.has_events = true;
   }
   if (partial_count > s.h_partial_cap) {
+    if (int rc = quiesce_for_allocation(ctx, "a page-locked result slot")) return rc;
     if (s.h_partial) HIP_TRY(ctx, hipHostFree(s.h_partial));
     s.h_partial = nullptr;
     // one extra record at the end receives the plan counters of the instance (work-item statistics for timings)
@@ -908,8 +970,8 @@ int submit_batch_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, s
     ctx->next_ws = (ctx->next_ws + 1) % kWorkspaces;
     int rc = enqueue_msm(ctx, w, B.slots[i], scalar_layout, point_layout, d_scalars[i], d_points[i], n[i], &B.plans[i],
                          lone);
-    if (rc) {   // nothing of a failed submit stays in flight; the batch slot was never marked active
-      drain_streams(ctx);
+    if (rc) {   // nothing of a failed submit stays in flight (or the ctx is marked stalled); the slot was never active
+      (void)drain_or_mark_stalled(ctx);
       return rc;
     }
   }
@@ -987,8 +1049,8 @@ int wait_batch(msm_amd_ctx* ctx, int ticket, bool internal = true) {
                       (internal ? "" : "; the ticket stays valid"));
     }
     if (done[i].err != hipSuccess) {   // release the ticket on every exit: a failed wait must not block later submits
-      drain_streams(ctx);
-      B.active = false;
+      if (!drain_or_mark_stalled(ctx)) B.abandoned = true;
+      else B.active = false;
       return fail(ctx, MSM_AMD_PIPELINE_ERROR, std::string("hipEventQuery: ") + hipGetErrorString(done[i].err));
     }
     accumulate_timings(ctx, B.slots[i], B.plans[i], done[i].final_ms, B.n_inst);
@@ -1053,6 +1115,7 @@ void stager_worker(Stager* S, int part) {
 int stager_prepare(msm_amd_ctx* ctx) {
   Stager& S = ctx->stager;
   if (S.ready) return MSM_AMD_OK;
+  if (int rc = quiesce_for_allocation(ctx, "the page-locked staging ring")) return rc;
   for (int k = 0; k < Stager::kSlots; ++k) {
     HIP_TRY(ctx, hipHostMalloc(&S.slot[k], Stager::kChunk, hipHostMallocDefault));
     HIP_TRY(ctx, hipEventCreateWithFlags(&S.sent[k], hipEventDisableTiming));
@@ -1176,9 +1239,36 @@ uint64_t hash_phase(const void* host, size_t n, size_t pb, size_t S, size_t phas
   return h;
 }
 
+// Full verification: the array as kCacheChunks contiguous slices, each hashed sequentially, the slices spread over a
+// few short-lived threads (a 64 MiB array: ~1.5 ms on four threads against ~12 ms on one).
+constexpr size_t kCacheChunks = 64;
+void hash_chunks(const void* host, size_t n, size_t pb, uint64_t* out) {
+  const uint8_t* base = (const uint8_t*)host;
+  auto one = [&](size_t c) {
+    const size_t lo = n * c / kCacheChunks, hi = n * (c + 1) / kCacheChunks;
+    uint64_t h = 0x13198A2E03707344ull ^ (uint64_t)n ^ ((uint64_t)c << 48);
+    for (size_t i = lo; i < hi; ++i) h = hash_record(h, base + i * pb, pb);
+    out[c] = h;
+  };
+  const size_t T = n * pb >= ((size_t)4 << 20) ? 4 : 1;
+  std::vector<std::thread> th;
+  try {
+    for (size_t t = 1; t < T; ++t)
+      th.emplace_back([&, t] { for (size_t c = t; c < kCacheChunks; c += T) one(c); });
+  } catch (...) {
+    for (std::thread& x : th) x.join();
+    th.clear();
+    for (size_t c = 0; c < kCacheChunks; ++c) one(c);
+    return;
+  }
+  const size_t started = th.size() + 1;
+  for (size_t c = 0; c < kCacheChunks; c += started) one(c);
+  for (std::thread& x : th) x.join();
+}
+
 void bases_cache_drop(msm_amd_ctx* ctx, size_t k) {
   BasesCacheEntry& e = ctx->bases_cache[k];
-  if (e.d_prepared) (void)hipFree(e.d_prepared);   // (an implicit device-wide synchronisation)
+  if (e.d_prepared) ctx->graveyard.push_back(e.d_prepared);   // hipFree waits for the whole device: later (reap_graveyard)
   ctx->bases_cache_bytes -= e.n * sizeof(AffPacked);
   ctx->bases_cache.erase(ctx->bases_cache.begin() + (long)k);
 }
@@ -1194,7 +1284,11 @@ BasesCacheEntry* bases_cache_lookup(msm_amd_ctx* ctx, const void* host, size_t n
     if (e.host != host || e.n != n || e.layout != layout) continue;
     const size_t pb = point_bytes(layout), S = e.phase_hash.size();
     bool same = hash_phase(host, n, pb, S, 0) == e.phase_hash[0];
-    if (same && S > 1) {
+    if (same && ctx->bases_cache_verify) {   // every record, every hit
+      uint64_t now[kCacheChunks];
+      hash_chunks(host, n, pb, now);
+      same = std::memcmp(now, e.chunk_hash.data(), sizeof now) == 0;
+    } else if (same && S > 1) {
       const uint32_t ph = e.next_phase;
       e.next_phase = ph + 1 >= S ? 1 : ph + 1;
       same = hash_phase(host, n, pb, S, ph) == e.phase_hash[ph];
@@ -1212,31 +1306,74 @@ BasesCacheEntry* bases_cache_lookup(msm_amd_ctx* ctx, const void* host, size_t n
   return nullptr;
 }
 
-// Miss: a new entry with room for the converted copy (least recently used entries of EARLIER calls make way), or
-// nullptr if the budget does not allow it -- the instance then runs uncached.
+// Start of a host-slice call: room on the device for those of its arrays that have no entry yet (least recently used
+// entries that this call will not hit make way).  The ctx is idle here or is waited for, bounded; an array that gets
+// no room runs uncached.
+void bases_cache_reserve(msm_amd_ctx* ctx, size_t n_inst, const void* const* points, const size_t* n, int layout) {
+  for (const msm_amd_ctx::CacheReserve& r : ctx->cache_reserve) ctx->graveyard.push_back(r.d);   // an earlier call's leftovers
+  ctx->cache_reserve.clear();
+  if (!ctx->bases_cache_budget) return;
+  auto has_key = [&](size_t j) {
+    for (const BasesCacheEntry& e : ctx->bases_cache)
+      if (e.host == points[j] && e.n == n[j] && e.layout == layout) return true;
+    for (const msm_amd_ctx::CacheReserve& r : ctx->cache_reserve)
+      if (r.host == points[j] && r.n == n[j] && r.layout == layout) return true;
+    return false;
+  };
+  for (size_t j = 0; j < n_inst; ++j)   // what this call is about to hit stays
+    for (BasesCacheEntry& e : ctx->bases_cache)
+      if (e.host == points[j] && e.n == n[j] && e.layout == layout) e.wanted_by = ctx->bases_cache_call;
+  bool idle = false;
+  size_t reserved_bytes = 0;
+  for (size_t j = 0; j < n_inst; ++j) {
+    if (!points[j] || has_key(j)) continue;
+    const size_t bytes = n[j] * sizeof(AffPacked);
+    if (bytes > ctx->bases_cache_budget) continue;
+    bool room = true;
+    while (ctx->bases_cache_bytes + reserved_bytes + bytes > ctx->bases_cache_budget) {
+      size_t victim = ctx->bases_cache.size();
+      for (size_t k = 0; k < ctx->bases_cache.size(); ++k)
+        if (ctx->bases_cache[k].last_use != ctx->bases_cache_call && ctx->bases_cache[k].wanted_by != ctx->bases_cache_call &&
+            (victim == ctx->bases_cache.size() || ctx->bases_cache[k].last_use < ctx->bases_cache[victim].last_use))
+          victim = k;
+      if (victim == ctx->bases_cache.size()) {
+        room = false;
+        break;
+      }
+      bases_cache_drop(ctx, victim);
+    }
+    if (!room) continue;
+    if (!idle) {
+      if (!streams_idle(ctx) && !drain_streams_bounded(ctx)) return;   // busy past the bound: this call runs uncached
+      idle = true;
+    }
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    ctx->cache_reserve.push_back({points[j], n[j], layout, d});
+    reserved_bytes += bytes;
+  }
+}
+
+// Miss: a new entry on the room bases_cache_reserve made for it, or nullptr -- the instance then runs uncached.
 BasesCacheEntry* bases_cache_insert(msm_amd_ctx* ctx, const void* host, size_t n, int layout) {
   const size_t bytes = n * sizeof(AffPacked);
-  if (bytes > ctx->bases_cache_budget) return nullptr;
   for (size_t k = 0; k < ctx->bases_cache.size(); ++k)   // a stale twin the lookup had to leave alone
     if (ctx->bases_cache[k].host == host && ctx->bases_cache[k].n == n && ctx->bases_cache[k].layout == layout)
       return nullptr;
-  while (ctx->bases_cache_bytes + bytes > ctx->bases_cache_budget) {
-    size_t victim = ctx->bases_cache.size();
-    for (size_t k = 0; k < ctx->bases_cache.size(); ++k)
-      if (ctx->bases_cache[k].last_use != ctx->bases_cache_call &&
-          (victim == ctx->bases_cache.size() || ctx->bases_cache[k].last_use < ctx->bases_cache[victim].last_use))
-        victim = k;
-    if (victim == ctx->bases_cache.size()) return nullptr;
-    bases_cache_drop(ctx, victim);
-  }
   BasesCacheEntry e;
   e.host = host;
   e.n = n;
   e.layout = layout;
-  if (hipMalloc(&e.d_prepared, bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
+  for (size_t k = 0; k < ctx->cache_reserve.size(); ++k)
+    if (ctx->cache_reserve[k].host == host && ctx->cache_reserve[k].n == n && ctx->cache_reserve[k].layout == layout) {
+      e.d_prepared = ctx->cache_reserve[k].d;
+      ctx->cache_reserve.erase(ctx->cache_reserve.begin() + (long)k);
+      break;
+    }
+  if (!e.d_prepared) return nullptr;
   const size_t pb = point_bytes(layout), S = cache_phases(n);
   e.phase_hash.assign(S, 0);
   for (size_t ph = 0; ph < S; ++ph) e.phase_hash[ph] = 0x243F6A8885A308D3ull ^ (uint64_t)n ^ ((uint64_t)ph << 40);
@@ -1246,6 +1383,8 @@ BasesCacheEntry* bases_cache_insert(msm_amd_ctx* ctx, const void* host, size_t n
     e.phase_hash[ph] = hash_record(e.phase_hash[ph], base + i * pb, pb);
     if (++ph == S) ph = 0;
   }
+  e.chunk_hash.assign(kCacheChunks, 0);
+  hash_chunks(host, n, pb, e.chunk_hash.data());
   e.last_use = ctx->bases_cache_call;
   ctx->bases_cache_bytes += bytes;
   ++ctx->bases_cache_misses;
@@ -1459,7 +1598,11 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
         if (t >= 0) ctx->batches[t].abandoned = true;
       return rc;
     }
-    (void)hipDeviceSynchronize();
+    if (!drain_or_mark_stalled(ctx)) {
+      for (int t : tickets)
+        if (t >= 0) ctx->batches[t].abandoned = true;
+      return rc;
+    }
     for (int t : tickets)
       if (t >= 0) ctx->batches[t].active = false;
     return rc;
@@ -1477,6 +1620,7 @@ int run_batch_host(msm_amd_ctx* ctx, int scalar_layout, int point_layout, size_t
   const bool lone = lone_call(ctx, n_inst);
   hipStream_t fs = front_stream_of(ctx, lone);
   const bool use_cache = ctx->bases_cache_budget != 0 && !dev_points;
+  if (use_cache) bases_cache_reserve(ctx, n_inst, points, n, point_layout);
   // bases cache (opt-in): a hit replaces the 64..96 B per point upload and the conversion by the resident converted
   // copy; a miss uploads as usual and converts straight into the new entry (the reference re-uploads and re-converts
   // the bases on every call, msm.rs:152-153; its callers pass the same SRS slice again and again,
@@ -1633,7 +1777,16 @@ int msm_amd_init(int device, msm_amd_ctx** out) {
             hipEventCreateWithFlags(&ctx->uploaded[1], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ctx->upload_done, hipEventDisableTiming) == hipSuccess;
   ctx->wait_timeout_ms = default_wait_timeout_ms();
-  if (const char* e = std::getenv("MSM_AMD_BASES_CACHE_MB")) ctx->bases_cache_budget = (size_t)std::strtoull(e, nullptr, 10) << 20;
+  if (const char* e = std::getenv("MSM_AMD_BASES_CACHE_VERIFY")) ctx->bases_cache_verify = std::strcmp(e, "full") == 0;
+  if (const char* e = std::getenv("MSM_AMD_BASES_CACHE_MB")) {
+    ctx->bases_cache_budget = (size_t)std::strtoull(e, nullptr, 10) << 20;
+    if (ctx->bases_cache_budget)   // switched on from OUTSIDE the calling code: say so, once per ctx
+      std::fprintf(stderr,
+                   "libmsm_amd: MSM_AMD_BASES_CACHE_MB=%s: host-slice entry points now reuse converted bases by (pointer, "
+                   "n, layout); a hit is verified %s -- callers that change bases in place must call "
+                   "msm_amd_bases_cache_invalidate\n",
+                   e, ctx->bases_cache_verify ? "in full (every record)" : "by sampling (MSM_AMD_BASES_CACHE_VERIFY=full re-hashes every record)");
+  }
   for (int k = 0; ok && k < kWorkspaces; ++k)
     ok = hipEventCreateWithFlags(&ctx->ws[k].front_done, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&ctx->ws[k].acc_done, hipEventDisableTiming) == hipSuccess &&
@@ -1747,9 +1900,11 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
   }
   ctx->live_tables.clear();
   for (DeviceBuf* b : {&ctx->scratch_a, &ctx->scratch_b, &ctx->scratch_c, &ctx->scratch_b2, &ctx->scratch_c2}) kill_buf(*b);
+  bases_cache_clear(ctx);   // (entries and unused reserves go through the graveyard)
+  for (const msm_amd_ctx::CacheReserve& r : ctx->cache_reserve) ctx->graveyard.push_back(r.d);
+  ctx->cache_reserve.clear();
   for (void* p : ctx->graveyard) (void)hipFree(p);
   ctx->graveyard.clear();
-  bases_cache_clear(ctx);
   for (Batch& B : ctx->batches) {
     for (InstanceSlot& s : B.slots) {
       if (s.h_partial) (void)hipHostFree(s.h_partial);
@@ -1795,8 +1950,8 @@ int msm_amd_host_unregister(msm_amd_ctx* ctx, const void* ptr) {
   for (size_t i = 0; i < ctx->host_regs.size(); ++i)
     if (ctx->host_regs[i].first == ptr) {
       HIP_TRY(ctx, hipSetDevice(ctx->device));
-      drain_streams(ctx);
-      (void)hipStreamSynchronize(ctx->copy_stream);
+      if (!drain_or_mark_stalled(ctx))   // DMA from this buffer may still be in flight
+        return fail(ctx, MSM_AMD_PIPELINE_ERROR, "device busy past the wait bound: the buffer stays registered");
       HIP_TRY(ctx, hipHostUnregister(const_cast<void*>(ptr)));
       ctx->host_regs.erase(ctx->host_regs.begin() + (long)i);
       return MSM_AMD_OK;
@@ -1837,6 +1992,25 @@ int msm_amd_set_bases_cache(msm_amd_ctx* ctx, size_t max_bytes) {
       if (ctx->bases_cache[k].last_use < ctx->bases_cache[victim].last_use) victim = k;
     bases_cache_drop(ctx, victim);
   }
+  return MSM_AMD_OK;
+}
+
+int msm_amd_set_bases_cache_verify(msm_amd_ctx* ctx, int full) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  ctx->bases_cache_verify = full ? 1 : 0;
+  return MSM_AMD_OK;
+}
+
+// The caller's word that the array at host_points changed (or NULL: everything): its entries are dropped.
+int msm_amd_bases_cache_invalidate(msm_amd_ctx* ctx, const void* host_points) {
+  if (!ctx) return MSM_AMD_INPUT_ERROR;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  for (size_t k = ctx->bases_cache.size(); k-- > 0;)
+    if (!host_points || ctx->bases_cache[k].host == host_points) {
+      ++ctx->bases_cache_invalidations;
+      bases_cache_drop(ctx, k);   // the device copy goes to the graveyard: safe under work in flight
+    }
   return MSM_AMD_OK;
 }
 
@@ -1889,8 +2063,8 @@ int msm_amd_gpu_msm_h2c_sync(msm_amd_ctx* ctx, const void* scalars, const void* 
                   "timed out after " + std::to_string(ctx->wait_timeout_ms) + " ms waiting for event 'sort' of the MSM");
     }
     if (e != hipSuccess) {
-      drain_streams(ctx);
-      ctx->batches[ticket].active = false;
+      if (!drain_or_mark_stalled(ctx)) ctx->batches[ticket].abandoned = true;
+      else ctx->batches[ticket].active = false;
       return fail(ctx, MSM_AMD_PIPELINE_ERROR, std::string("hipEventSynchronize(sort): ") + hipGetErrorString(e));
     }
     // a GPU-clock mark of "now" on a stream that has nothing queued: after the MSM has finished, the device time
@@ -2019,6 +2193,7 @@ int msm_amd_msm_best(msm_amd_ctx* ctx, const void* scalars, const void* points, 
   BasesCacheEntry* hit = nullptr;
   AffPacked* fill = nullptr;
   if (ctx->bases_cache_budget) {
+    bases_cache_reserve(ctx, 1, &points, &n, MSM_AMD_POINT_H2C_AFFINE);
     if ((hit = bases_cache_lookup(ctx, points, n, MSM_AMD_POINT_H2C_AFFINE)) == nullptr)
       if (BasesCacheEntry* f = bases_cache_insert(ctx, points, n, MSM_AMD_POINT_H2C_AFFINE)) fill = (AffPacked*)f->d_prepared;
   }
@@ -2026,22 +2201,39 @@ int msm_amd_msm_best(msm_amd_ctx* ctx, const void* scalars, const void* points, 
     dp = hit->d_prepared;
     pt_layout = MSM_AMD_POINT_PREPARED;
   } else {
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch_c.p, points, n * 64, hipMemcpyHostToDevice, st));
-    if (fill) {
+    // an entry that was inserted for this call but never (provably) written must not be hit later: on any failure
+    // from here to the end of the fill its key is cleared
+    auto unkey = [&]() {
+      if (fill)
+        for (BasesCacheEntry& c : ctx->bases_cache)
+          if (c.d_prepared == (void*)fill) c.host = nullptr;
+    };
+    hipError_t he = hipMemcpyAsync(ctx->scratch_c.p, points, n * 64, hipMemcpyHostToDevice, st);
+    if (he == hipSuccess && fill) {
       launch_convert_bases(st, (const Affine*)ctx->scratch_c.p, (uint32_t)n, fill);
-      HIP_TRY(ctx, hipGetLastError());
+      he = hipGetLastError();
       dp = fill;
       pt_layout = MSM_AMD_POINT_PREPARED;
     }
+    if (he == hipSuccess) {
+      if (int src_ = sync_stream_bounded(ctx, st, "msm_best upload")) {
+        unkey();
+        return src_;
+      }
+    }
+    if (he != hipSuccess) {
+      unkey();
+      HIP_TRY(ctx, he);
+    }
   }
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (int src_ = sync_stream_bounded(ctx, st, __func__)) return src_;
   const double zero_ratio = (double)(n - survivors) / (double)n;
   const void* ds = ctx->scratch_b.p;
   size_t m = n;
   if (zero_ratio >= 0.30) {   // msm.rs:470
     launch_filter_scatter(st, (const u256*)ctx->scratch_b.p, (const Affine*)dp, (uint32_t)n, counts, f_sc, f_pt);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(st));   // run_batch_device starts on the front stream
+    if (int src_ = sync_stream_bounded(ctx, st, __func__)) return src_;   // run_batch_device starts on the front stream
     ds = f_sc;
     dp = f_pt;
     m = survivors;
@@ -2091,7 +2283,7 @@ int msm_amd_msm_device(msm_amd_ctx* ctx, int scalar_layout, int point_layout, co
 // Conversion of a resident point array to the internal packed form; ctx->mu held by the caller.
 static int prepare_bases_locked(msm_amd_ctx* ctx, int point_layout, const void* d_points, size_t n, void* d_prepared) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipDeviceSynchronize());   // a set-up step: the conversion scratch of workspace 0 must be idle
+  if (!drain_or_mark_stalled(ctx)) return fail(ctx, MSM_AMD_PIPELINE_ERROR, "device busy past the wait bound");   // a set-up step: the conversion scratch of workspace 0 must be idle
   hipStream_t st = ctx->stream;
   const u256* sc = nullptr;
   const Affine* pts = nullptr;
@@ -2101,7 +2293,7 @@ static int prepare_bases_locked(msm_amd_ctx* ctx, int point_layout, const void* 
     return rc;
   launch_convert_bases(st, pts, (uint32_t)n, (AffPacked*)d_prepared);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (int src_ = sync_stream_bounded(ctx, st, __func__)) return src_;
   return MSM_AMD_OK;
 }
 
@@ -2125,6 +2317,7 @@ int msm_amd_bases_upload(msm_amd_ctx* ctx, int point_layout, const void* points,
   int rc;
   if ((rc = ensure(ctx, ctx->scratch_c, n * pb))) return rc;
   void* d_out = nullptr;
+  if (int qrc = quiesce_for_allocation(ctx, "the resident copy of the bases")) return qrc;
   HIP_TRY(ctx, hipMalloc(&d_out, n * sizeof(AffPacked)));
   hipError_t e = hipMemcpy(ctx->scratch_c.p, points, n * pb, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -2168,7 +2361,7 @@ static int tables_build_locked(msm_amd_ctx* ctx, int point_layout, const void* d
   const uint32_t W = kModulusBits / c + 1;
   if ((size_t)W * n > 0x7FFFFFFFull) return fail(ctx, MSM_AMD_INPUT_ERROR, "windows * n must stay below 2^31");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipDeviceSynchronize());   // a set-up step: the conversion scratch of workspace 0 must be idle
+  if (!drain_or_mark_stalled(ctx)) return fail(ctx, MSM_AMD_PIPELINE_ERROR, "device busy past the wait bound");   // a set-up step: the conversion scratch of workspace 0 must be idle
   hipStream_t st = ctx->stream;
   const u256* sc = nullptr;
   const Affine* pts = nullptr;
@@ -2179,10 +2372,14 @@ static int tables_build_locked(msm_amd_ctx* ctx, int point_layout, const void* d
                            &sc_mont, &pts)))
     return rc;
   void* d_tab = nullptr;
+  if (int qrc = quiesce_for_allocation(ctx, "the window tables")) return qrc;
   HIP_TRY(ctx, hipMalloc(&d_tab, (size_t)W * n * sizeof(AffPacked)));
   launch_build_tables(st, pts, (uint32_t)n, c, W, (AffPacked*)d_tab);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess && sync_stream_bounded(ctx, st, "table build")) {
+    ctx->graveyard.push_back(d_tab);   // the build may still be running: released when the ctx is idle
+    return MSM_AMD_PIPELINE_ERROR;
+  }
   if (e != hipSuccess) {
     (void)hipFree(d_tab);
     HIP_TRY(ctx, e);
@@ -2239,9 +2436,9 @@ int msm_amd_tables_free(msm_amd_ctx* ctx, msm_amd_tables* tables) {
   auto it = std::find(ctx->live_tables.begin(), ctx->live_tables.end(), tables);
   if (it == ctx->live_tables.end()) return fail(ctx, MSM_AMD_INPUT_ERROR, "not a table handle of this ctx");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipDeviceSynchronize());
   ctx->live_tables.erase(it);
-  (void)hipFree(tables->d_tables);
+  if (drain_or_mark_stalled(ctx)) (void)hipFree(tables->d_tables);
+  else ctx->graveyard.push_back(tables->d_tables);   // hipFree would wait for the device without bound
   delete tables;
   return MSM_AMD_OK;
 }
@@ -2289,6 +2486,7 @@ int msm_amd_device_alloc(msm_amd_ctx* ctx, size_t bytes, void** d_ptr) {
   if (!ctx || !d_ptr || bytes == 0) return fail(ctx, MSM_AMD_INPUT_ERROR, "bad device_alloc arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rc = quiesce_for_allocation(ctx, "device memory (msm_amd_device_alloc)")) return rc;
   HIP_TRY(ctx, hipMalloc(d_ptr, bytes));
   return MSM_AMD_OK;
 }
@@ -2297,7 +2495,11 @@ int msm_amd_device_free(msm_amd_ctx* ctx, void* d_ptr) {
   if (!ctx) return MSM_AMD_INPUT_ERROR;
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (!d_ptr) return MSM_AMD_OK;
+  if (!drain_streams_bounded(ctx)) {   // the device does not answer: hipFree would wait for it without bound
+    ctx->graveyard.push_back(d_ptr);   // released once the ctx is idle again, or at msm_amd_destroy
+    return MSM_AMD_OK;
+  }
   HIP_TRY(ctx, hipFree(d_ptr));
   return MSM_AMD_OK;
 }
@@ -2307,7 +2509,7 @@ int msm_amd_copy_to_device(msm_amd_ctx* ctx, void* d_dst, const void* h_src, siz
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int src_ = sync_stream_bounded(ctx, ctx->stream, __func__)) return src_;
   return MSM_AMD_OK;
 }
 
@@ -2316,7 +2518,7 @@ int msm_amd_copy_to_host(msm_amd_ctx* ctx, void* h_dst, const void* d_src, size_
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int src_ = sync_stream_bounded(ctx, ctx->stream, __func__)) return src_;
   return MSM_AMD_OK;
 }
 
@@ -2345,7 +2547,7 @@ int msm_amd_generate_instance(msm_amd_ctx* ctx, uint64_t seed, size_t n, int sca
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   launch_gen_instance(ctx->stream, seed, (uint32_t)n, scalars_mont, (Affine*)d_points, (u256*)d_scalars);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int src_ = sync_stream_bounded(ctx, ctx->stream, __func__)) return src_;
   return MSM_AMD_OK;
 }
 
@@ -2368,7 +2570,7 @@ int msm_amd_prepare_buckets_indices(msm_amd_ctx* ctx, const uint32_t* scalars_be
                      (uint2*)ctx->scratch_c.p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(pairs_out, ctx->scratch_c.p, pair_bytes, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (int src_ = sync_stream_bounded(ctx, st, __func__)) return src_;
   return MSM_AMD_OK;
 }
 
@@ -2390,7 +2592,7 @@ int msm_amd_sort_buckets_indices(msm_amd_ctx* ctx, uint32_t* pairs, size_t n_pai
                           (uint32_t*)ctx->scratch_c.p, &src);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(pairs, src, n_pairs * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (int src_ = sync_stream_bounded(ctx, st, __func__)) return src_;
   return MSM_AMD_OK;
 }
 
@@ -2417,7 +2619,7 @@ int msm_amd_sort_pairs_device(msm_amd_ctx* ctx, void* d_pairs, size_t n_pairs, u
   if (le == hipSuccess && src != (uint2*)d_pairs)   // odd number of passes: the result sits in the scratch buffer
     le = hipMemcpyAsync(d_pairs, src, n_pairs * 8, hipMemcpyDeviceToDevice, st);
   if (le == hipSuccess) le = hipEventRecord(e1, st);
-  if (le == hipSuccess) le = hipStreamSynchronize(st);
+  if (le == hipSuccess && sync_stream_bounded(ctx, st, "pair sort")) le = hipErrorNotReady;
   float ms = 0.f;
   if (le == hipSuccess) le = hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0);
@@ -2434,7 +2636,8 @@ int msm_amd_bucket_wise_accumulation(msm_amd_ctx* ctx, const uint32_t* sorted_pa
     return fail(ctx, MSM_AMD_INPUT_ERROR, "bad bucket_wise_accumulation arguments");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  drain_streams(ctx);   // workspace 0 may belong to an MSM between submit_batch_device and wait_batch
+  if (!drain_or_mark_stalled(ctx))   // workspace 0 may belong to an MSM between submit_batch_device and wait_batch
+    return fail(ctx, MSM_AMD_PIPELINE_ERROR, "device busy past the wait bound");
   hipStream_t st = ctx->stream;
   int rc;
   const size_t pts_bytes = n_points * 96, bkt_bytes = (size_t)total_buckets * 96;
@@ -2454,7 +2657,7 @@ int msm_amd_bucket_wise_accumulation(msm_amd_ctx* ctx, const uint32_t* sorted_pa
   launch_be32_to_le(st, (const uint32_t*)ctx->ws[0].buckets.p, (size_t)total_buckets * 3, (uint32_t*)ctx->scratch_a.p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(buckets_out, ctx->scratch_a.p, bkt_bytes, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (int src_ = sync_stream_bounded(ctx, st, __func__)) return src_;
   return MSM_AMD_OK;
 }
 
@@ -2468,7 +2671,8 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   if (c > 24) return fail(ctx, MSM_AMD_INPUT_ERROR, "buckets_size too large");
   std::lock_guard<std::mutex> g(ctx->mu);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  drain_streams(ctx);   // workspace 0 may belong to an MSM between submit_batch_device and wait_batch
+  if (!drain_or_mark_stalled(ctx))   // workspace 0 may belong to an MSM between submit_batch_device and wait_batch
+    return fail(ctx, MSM_AMD_PIPELINE_ERROR, "device busy past the wait bound");
   hipStream_t st = ctx->stream;
   const Plan p = make_reduce_plan(c, num_windows);
   int rc;
@@ -2484,7 +2688,7 @@ int msm_amd_sum_reduction(msm_amd_ctx* ctx, const uint32_t* buckets_be32, uint32
   std::vector<Jacobian> partial(p.partial_count);
   HIP_TRY(ctx, hipMemcpyAsync(partial.data(), ctx->ws[0].partial.p, p.partial_count * sizeof(Jacobian),
                               hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (int src_ = sync_stream_bounded(ctx, st, __func__)) return src_;
   // per-window value: reuse the fused Horner with a single window
   Plan one = p;
   one.W = 1;
@@ -2558,7 +2762,7 @@ int msm_amd_test_op(msm_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t*
                  (uint32_t)count);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(lo.data(), ctx->scratch_c.p, lo.size() * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (int src_ = sync_stream_bounded(ctx, st, __func__)) return src_;
   for (size_t i = 0; i < count * wo; ++i)
     for (int l = 0; l < 8; ++l) out[i * 8 + l] = lo[i * 8 + 7 - l];
   return MSM_AMD_OK;

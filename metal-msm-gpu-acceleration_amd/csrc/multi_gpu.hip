@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -59,6 +60,29 @@ bool read_line(const std::string& path, char* buf, size_t len) {
   if (!f) return false;
   const bool ok = std::fgets(buf, (int)len, f) != nullptr;
   std::fclose(f);
+  return ok;
+}
+
+// body(k) for every ctx k < G: the caller's thread takes ctx 0, one short-lived thread each for the others (pinned to
+// the CPUs local to their GPU).  false = a thread could not be started (the ctxs without a thread did not run).
+template <class F>
+bool for_each_ctx_threaded(size_t G, bool pin, msm_amd_ctx* const* ctxs, F&& body) {
+  std::vector<std::thread> threads;
+  bool ok = true;
+  auto run = [&](size_t k, bool pin_this) {
+    cpu_set_t before;
+    const bool restore = pin_this && sched_getaffinity(0, sizeof before, &before) == 0;
+    if (pin_this) (void)msm_amd_pin_thread_to_device(msm_amd_ctx_device(ctxs[k]));
+    body(k);
+    if (restore) (void)sched_setaffinity(0, sizeof before, &before);
+  };
+  try {
+    for (size_t k = 1; k < G; ++k) threads.emplace_back(run, k, pin);
+  } catch (...) {
+    ok = false;
+  }
+  if (ok) run(0, pin && G > 1);
+  for (std::thread& t : threads) t.join();
   return ok;
 }
 
@@ -109,36 +133,52 @@ static int batch_multi(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout
       if (ctxs[l] == ctxs[k]) return MSM_AMD_INPUT_ERROR;   // one thread per ctx: a ctx listed twice would serialise
   }
   const size_t G = std::min(n_ctx, n_inst);
-  std::vector<int> rc(G, MSM_AMD_OK);
-  auto run = [&](size_t k, bool pin) {
-    cpu_set_t before;
-    const bool restore = pin && sched_getaffinity(0, sizeof before, &before) == 0;
-    if (pin) (void)msm_amd_pin_thread_to_device(msm_amd_ctx_device(ctxs[k]));
-    const size_t cnt = msm_amd_shard_count(n_inst, G, k);
-    std::vector<const void*> sp(cnt), pp(cnt);
-    std::vector<size_t> nn(cnt);
-    std::vector<uint8_t> res(cnt * 96);
-    for (size_t i = 0; i < cnt; ++i) {
-      const size_t j = k + i * G;
-      sp[i] = scalars[j];
-      pp[i] = points[j];
-      nn[i] = n[j];
+  // nothing below may throw across the C boundary: allocation failures and std::system_error from thread creation
+  // become MSM_AMD_PIPELINE_ERROR, with every thread that did start joined first
+  try {
+    std::vector<int> rc(G, MSM_AMD_OK);
+    auto run = [&](size_t k, bool pin) {
+      try {
+        cpu_set_t before;
+        const bool restore = pin && sched_getaffinity(0, sizeof before, &before) == 0;
+        if (pin) (void)msm_amd_pin_thread_to_device(msm_amd_ctx_device(ctxs[k]));
+        const size_t cnt = msm_amd_shard_count(n_inst, G, k);
+        std::vector<const void*> sp(cnt), pp(cnt);
+        std::vector<size_t> nn(cnt);
+        std::vector<uint8_t> res(cnt * 96);
+        for (size_t i = 0; i < cnt; ++i) {
+          const size_t j = k + i * G;
+          sp[i] = scalars[j];
+          pp[i] = points[j];
+          nn[i] = n[j];
+        }
+        rc[k] = device ? msm_amd_msm_batch_device(ctxs[k], scalar_layout, point_layout, cnt, sp.data(), pp.data(),
+                                                  nn.data(), res.data())
+                       : msm_amd_msm_batch(ctxs[k], scalar_layout, point_layout, cnt, sp.data(), pp.data(), nn.data(),
+                                           res.data());
+        if (rc[k] == MSM_AMD_OK)
+          for (size_t i = 0; i < cnt; ++i) std::memcpy((uint8_t*)out + (k + i * G) * 96, res.data() + i * 96, 96);
+        if (restore) (void)sched_setaffinity(0, sizeof before, &before);   // the caller's thread gets its mask back
+      } catch (...) {
+        rc[k] = MSM_AMD_PIPELINE_ERROR;
+      }
+    };
+    std::vector<std::thread> threads;
+    bool spawn_failed = false;
+    try {
+      for (size_t k = 1; k < G; ++k) threads.emplace_back(run, k, true);
+    } catch (...) {
+      spawn_failed = true;   // the ctxs whose thread did not start simply do not run
     }
-    rc[k] = device ? msm_amd_msm_batch_device(ctxs[k], scalar_layout, point_layout, cnt, sp.data(), pp.data(), nn.data(),
-                                              res.data())
-                   : msm_amd_msm_batch(ctxs[k], scalar_layout, point_layout, cnt, sp.data(), pp.data(), nn.data(),
-                                       res.data());
-    if (rc[k] == MSM_AMD_OK)
-      for (size_t i = 0; i < cnt; ++i) std::memcpy((uint8_t*)out + (k + i * G) * 96, res.data() + i * 96, 96);
-    if (restore) (void)sched_setaffinity(0, sizeof before, &before);   // the caller's thread gets its mask back
-  };
-  std::vector<std::thread> threads;
-  for (size_t k = 1; k < G; ++k) threads.emplace_back(run, k, true);
-  run(0, G > 1);
-  for (std::thread& t : threads) t.join();
-  for (size_t k = 0; k < G; ++k)
-    if (rc[k]) return rc[k];
-  return MSM_AMD_OK;
+    run(0, G > 1);
+    for (std::thread& t : threads) t.join();
+    if (spawn_failed) return MSM_AMD_PIPELINE_ERROR;
+    for (size_t k = 0; k < G; ++k)
+      if (rc[k]) return rc[k];
+    return MSM_AMD_OK;
+  } catch (...) {
+    return MSM_AMD_PIPELINE_ERROR;
+  }
 }
 
 int msm_amd_msm_batch_multi(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout, size_t n_inst,
@@ -150,6 +190,99 @@ int msm_amd_msm_batch_multi_device(msm_amd_ctx* const* ctxs, size_t n_ctx, int s
                                    size_t n_inst, const void* const* d_scalars, const void* const* d_points,
                                    const size_t* n, void* out_host) {
   return batch_multi(ctxs, n_ctx, scalar_layout, point_layout, n_inst, d_scalars, d_points, n, out_host, 1);
+}
+
+// Pipelined form of msm_amd_msm_batch_multi_device: submit enqueues the share of every ctx (msm_amd_submit_batch_device,
+// one short-lived host thread per ctx so that eight GPUs are fed side by side) and returns; wait finishes every share
+// (the host Horner passes, again one thread per ctx) and scatters the results to out_host + 96 j.  Up to four such
+// batches may be in flight per ctx, so a caller that loops -- the reference's benchmark loop,
+// benches/msm_benchmark.rs:29-34 -- keeps every GPU's pipeline full across calls instead of paying the call-boundary
+// bubble of the blocking form once per batch.
+struct msm_amd_multi_ticket {
+  std::vector<msm_amd_ctx*> ctxs;
+  std::vector<int> tickets;                 // per ctx, -1 = nothing submitted
+  std::vector<std::vector<uint8_t>> res;    // per ctx: its results, contiguous
+  size_t n_inst = 0;
+  uint8_t* out = nullptr;
+};
+
+int msm_amd_submit_batch_multi_device(msm_amd_ctx* const* ctxs, size_t n_ctx, int scalar_layout, int point_layout,
+                                      size_t n_inst, const void* const* d_scalars, const void* const* d_points,
+                                      const size_t* n, void* out_host, msm_amd_multi_ticket** ticket) {
+  if (ticket) *ticket = nullptr;
+  if (!ctxs || n_ctx == 0 || !d_scalars || !d_points || !n || !out_host || !ticket || n_inst == 0)
+    return MSM_AMD_INPUT_ERROR;
+  for (size_t k = 0; k < n_ctx; ++k) {
+    if (!ctxs[k]) return MSM_AMD_INPUT_ERROR;
+    for (size_t l = 0; l < k; ++l)
+      if (ctxs[l] == ctxs[k]) return MSM_AMD_INPUT_ERROR;
+  }
+  try {
+    const size_t G = std::min(n_ctx, n_inst);
+    std::unique_ptr<msm_amd_multi_ticket> t(new msm_amd_multi_ticket());
+    t->ctxs.assign(ctxs, ctxs + G);
+    t->tickets.assign(G, -1);
+    t->res.resize(G);
+    t->n_inst = n_inst;
+    t->out = (uint8_t*)out_host;
+    for (size_t k = 0; k < G; ++k) t->res[k].resize(msm_amd_shard_count(n_inst, G, k) * 96);
+    std::vector<int> rc(G, MSM_AMD_OK);
+    const bool spawned = for_each_ctx_threaded(G, true, ctxs, [&](size_t k) {
+      try {
+        const size_t cnt = msm_amd_shard_count(n_inst, G, k);
+        std::vector<const void*> sp(cnt), pp(cnt);
+        std::vector<size_t> nn(cnt);
+        for (size_t i = 0; i < cnt; ++i) {
+          const size_t j = k + i * G;
+          sp[i] = d_scalars[j];
+          pp[i] = d_points[j];
+          nn[i] = n[j];
+        }
+        rc[k] = msm_amd_submit_batch_device(ctxs[k], scalar_layout, point_layout, cnt, sp.data(), pp.data(), nn.data(),
+                                            t->res[k].data(), &t->tickets[k]);
+      } catch (...) {
+        rc[k] = MSM_AMD_PIPELINE_ERROR;
+      }
+    });
+    int first = spawned ? MSM_AMD_OK : MSM_AMD_PIPELINE_ERROR;
+    for (size_t k = 0; k < G && !first; ++k) first = rc[k];
+    if (first) {   // finish what did get submitted: its result buffers die with the ticket
+      for (size_t k = 0; k < G; ++k)
+        if (t->tickets[k] >= 0 && rc[k] == MSM_AMD_OK) (void)msm_amd_wait_batch(ctxs[k], t->tickets[k]);
+      return first;
+    }
+    *ticket = t.release();
+    return MSM_AMD_OK;
+  } catch (...) {
+    return MSM_AMD_PIPELINE_ERROR;
+  }
+}
+
+// Finishes a batch of msm_amd_submit_batch_multi_device and frees the ticket -- unless a ctx's wait ran into the
+// bounded-wait limit (MSM_AMD_PIPELINE_ERROR with the work still in flight, msm_amd_set_wait_timeout_ms): the ticket
+// then stays valid and may be waited for again, like a ticket of msm_amd_submit_batch_device.
+int msm_amd_wait_batch_multi(msm_amd_multi_ticket* t) {
+  if (!t) return MSM_AMD_INPUT_ERROR;
+  try {
+    const size_t G = t->ctxs.size();
+    std::vector<int> rc(G, MSM_AMD_OK);
+    const bool spawned = for_each_ctx_threaded(G, true, t->ctxs.data(), [&](size_t k) {
+      if (t->tickets[k] < 0) return;
+      rc[k] = msm_amd_wait_batch(t->ctxs[k], t->tickets[k]);
+      if (rc[k] == MSM_AMD_OK) {
+        t->tickets[k] = -1;
+        const size_t cnt = t->res[k].size() / 96;
+        for (size_t i = 0; i < cnt; ++i) std::memcpy(t->out + (k + i * G) * 96, t->res[k].data() + i * 96, 96);
+      }
+    });
+    if (!spawned) return MSM_AMD_PIPELINE_ERROR;   // nothing lost: the tickets not waited for are still in t
+    for (size_t k = 0; k < G; ++k)
+      if (rc[k]) return rc[k];
+    delete t;
+    return MSM_AMD_OK;
+  } catch (...) {
+    return MSM_AMD_PIPELINE_ERROR;
+  }
 }
 
 // ONE instance over several ctxs, split by point range: ctx g runs the MSM of points [begin_g, end_g) over all

@@ -32,7 +32,9 @@ def rank_environments(nproc: int, master_port: int, base_env=None, master_addr: 
         raise ValueError("nproc must be >= 1")
     import os
     base = dict(os.environ if base_env is None else base_env)
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    # HSA_ENABLE_IPC_MODE_LEGACY is INHERITED, never defaulted here: which setting a host's driver wants (dmabuf or
+    # legacy IPC handles between the ranks' processes) is the operator's knowledge; launch_local_ranks tries the other
+    # one once when the ranks cannot even set up their communicator
     envs = []
     for r in range(nproc):
         e = dict(base)
@@ -49,16 +51,21 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def launch_local_ranks(nproc: int, argv, master_port: int = 0, base_env=None, timeout=None) -> int:
-    """Start `nproc` worker processes (`argv` = full command line, e.g. [sys.executable, "bench.py", ...]), one per
-    GPU, and wait for them.  The caller must NOT have touched the GPU: workers are plain children (subprocess), the
-    parent is never replaced.  Rank 0 inherits stdout (it prints the result line).  Returns 0 only when EVERY rank
-    exited 0; when one rank fails the others are terminated (a rank that died would leave the rest in a collective
-    forever) and the first non-zero code is returned."""
+IPC_VAR = "HSA_ENABLE_IPC_MODE_LEGACY"
+
+
+def _run_ranks(nproc, argv, envs, rank_dir, timeout):
+    """One attempt: start the children, wait.  Returns (exit code, ranks that reported "started")."""
+    import os
     import subprocess
     import time
-    envs = rank_environments(nproc, master_port or free_port(), base_env)
-    procs = [subprocess.Popen(list(argv), env=e) for e in envs]
+    procs, errs = [], []
+    for r, e in enumerate(envs):
+        e = dict(e)
+        e["MSM_AMD_RANK_STARTED_FILE"] = os.path.join(rank_dir, "rank%d.started" % r)
+        f = open(os.path.join(rank_dir, "rank%d.err" % r), "wb")
+        errs.append(f)
+        procs.append(subprocess.Popen(list(argv), env=e, stderr=f))   # stdout: inherited (rank 0 prints the line)
     deadline = None if timeout is None else time.monotonic() + timeout
     rc = 0
     try:
@@ -86,6 +93,60 @@ def launch_local_ranks(nproc: int, argv, master_port: int = 0, base_env=None, ti
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
+        for f in errs:
+            f.close()
+    started = [r for r in range(nproc) if os.path.exists(os.path.join(rank_dir, "rank%d.started" % r))]
+    return rc, started
+
+
+def launch_local_ranks(nproc: int, argv, master_port: int = 0, base_env=None, timeout=None, rank_dir=None,
+                       retry_other_ipc_mode=True, log=None) -> int:
+    """Start `nproc` worker processes (`argv` = full command line, e.g. [sys.executable, "bench.py", ...]), one per
+    GPU, and wait for them.  The caller must NOT have touched the GPU: workers are plain children (subprocess), the
+    parent is never replaced.  Rank 0 inherits stdout (it prints the result line); every rank's stderr goes to
+    `rank_dir`/rank<k>.err (a fresh temporary directory by default) and is replayed on the parent's stderr at the end,
+    so a rank that dies in communicator setup leaves its RCCL / HIP error text behind.  Returns 0 only when EVERY
+    rank exited 0; when one rank fails the others are terminated (a rank that died would leave the rest in a
+    collective forever) and the first non-zero code is returned.
+
+    First contact with a multi-GPU host: a worker touches the file named by MSM_AMD_RANK_STARTED_FILE once its
+    process group works (bench.py: after the first barrier).  If a rank fails before every rank has done so, and
+    `retry_other_ipc_mode` is set, the parent -- which never touched the GPU -- starts ONE fresh set of children with
+    HSA_ENABLE_IPC_MODE_LEGACY flipped (dmabuf <-> legacy IPC handles: cross-process sharing fails with
+    `hipIpcGetMemHandle: invalid argument` under the wrong one) and says which setting worked."""
+    import os
+    import sys
+    import tempfile
+    log = log or (lambda msg: print(msg, file=sys.stderr, flush=True))
+    base = dict(os.environ if base_env is None else base_env)
+    attempts = [base]
+    if retry_other_ipc_mode and nproc > 1:
+        other = dict(base)
+        other[IPC_VAR] = "1" if base.get(IPC_VAR, "") == "0" else "0"
+        attempts.append(other)
+    rc = 1
+    for k, env in enumerate(attempts):
+        d = tempfile.mkdtemp(prefix="msm_amd_ranks_") if rank_dir is None else os.path.join(rank_dir, "attempt%d" % k)
+        os.makedirs(d, exist_ok=True)
+        envs = rank_environments(nproc, master_port or free_port(), env)
+        rc, started = _run_ranks(nproc, argv, envs, d, timeout)
+        setting = "%s=%s" % (IPC_VAR, env.get(IPC_VAR, "<unset>"))
+        for r in range(nproc):                # replay what the ranks wrote (rank 0 first), failures or not
+            try:
+                text = open(os.path.join(d, "rank%d.err" % r), "rb").read().decode("utf-8", "replace")
+            except OSError:
+                text = ""
+            if text and (rc != 0 or r == 0):
+                sys.stderr.write("".join("[rank %d] %s\n" % (r, ln) for ln in text.splitlines()[-60:]))
+        if rc == 0:
+            if k > 0:
+                log("launch_local_ranks: the ranks came up with %s (the inherited setting failed in communicator setup)"
+                    % setting)
+            return 0
+        log("launch_local_ranks: a rank failed (exit %d) with %s; ranks that had a working process group: %s; "
+            "per-rank stderr in %s" % (rc, setting, started or "none", d))
+        if len(started) == nproc:
+            break                             # the failure came after communicator setup: the other IPC mode is no cure
     return rc
 
 

@@ -21,7 +21,9 @@ def test_rank_environments():
     assert [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2", "3"]
     assert all(e["WORLD_SIZE"] == "4" and e["LOCAL_WORLD_SIZE"] == "4" for e in envs)
     assert all(e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29517" for e in envs)
-    assert all(e["PATH"] == "/bin" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
+    assert all(e["PATH"] == "/bin" and "HSA_ENABLE_IPC_MODE_LEGACY" not in e for e in envs)     # inherited, never defaulted
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+               for e in mg.rank_environments(2, 1, base_env={"HSA_ENABLE_IPC_MODE_LEGACY": "1"}))
     with pytest.raises(ValueError):
         mg.rank_environments(0, 1)
 
@@ -53,6 +55,44 @@ def test_launcher_kills_the_survivors_of_a_failed_rank(tmp_path):
     hang = "import os, sys, time\nif os.environ['RANK'] == '0': sys.exit(5)\ntime.sleep(600)\n"
     rc = mg.launch_local_ranks(2, [sys.executable, "-c", hang], timeout=60)
     assert rc == 5
+
+
+FIRST_CONTACT = r"""
+import os, sys
+mode = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "<unset>")
+if mode != sys.argv[1]:
+    print("hipIpcGetMemHandle: invalid argument (stub) with mode", mode, file=sys.stderr)
+    sys.exit(3)
+open(os.environ["MSM_AMD_RANK_STARTED_FILE"], "w").close()
+if len(sys.argv) > 2 and os.environ["RANK"] == "1":
+    sys.exit(int(sys.argv[2]))
+"""
+
+
+def test_first_contact_failure_is_retried_once_with_the_other_ipc_mode(tmp_path):
+    """A rank that dies before its process group works: the parent starts ONE fresh set of children with
+    HSA_ENABLE_IPC_MODE_LEGACY flipped, says which setting worked, and keeps every rank's stderr."""
+    said = []
+    base = {k: v for k, v in os.environ.items()}
+    base["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    rc = mg.launch_local_ranks(2, [sys.executable, "-c", FIRST_CONTACT, "1"], base_env=base, timeout=60,
+                               rank_dir=str(tmp_path), log=said.append)
+    assert rc == 0
+    assert any("came up with HSA_ENABLE_IPC_MODE_LEGACY=1" in m for m in said)
+    assert "invalid argument (stub) with mode 0" in (tmp_path / "attempt0" / "rank0.err").read_text()
+    # inherited setting works: one attempt, nothing said about modes
+    said.clear()
+    assert mg.launch_local_ranks(2, [sys.executable, "-c", FIRST_CONTACT, "0"], base_env=base, timeout=60,
+                                 rank_dir=str(tmp_path / "b"), log=said.append) == 0 and not said
+    # a failure AFTER every rank's group worked is not retried
+    said.clear()
+    rc = mg.launch_local_ranks(2, [sys.executable, "-c", FIRST_CONTACT, "0", "9"], base_env=base, timeout=60,
+                               rank_dir=str(tmp_path / "c"), log=said.append)
+    assert rc == 9 and len(said) == 1 and not (tmp_path / "c" / "attempt1").exists()
+    # neither mode works: two attempts, the failure is reported
+    rc = mg.launch_local_ranks(2, [sys.executable, "-c", FIRST_CONTACT, "7"], base_env=base, timeout=60,
+                               rank_dir=str(tmp_path / "d"), log=said.append)
+    assert rc == 3 and (tmp_path / "d" / "attempt1" / "rank1.err").exists()
 
 
 def test_resolve_world():

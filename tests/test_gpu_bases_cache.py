@@ -110,3 +110,50 @@ def test_budget_and_eviction(ccfg, msm_pkg):
     proj = b"".join(pts[64 * i:64 * i + 64] + o.int_to_le_bytes32(o.fq_to_mont(1)) for i in range(n))
     for _ in range(2):
         assert _same(msm_pkg.metal_msm(proj, sc, ccfg), want[0])
+
+
+def test_full_verification_catches_any_mutated_record_on_the_first_call(ccfg, msm_pkg):
+    """msm_amd_set_bases_cache_verify(full): EVERY record of the caller's array is re-hashed on every hit, so a single
+    changed record outside phase 0 -- which the sampled check may miss for up to n / 1024 calls -- is caught by the
+    very next call.  msm_amd_bases_cache_invalidate is the explicit form of the same."""
+    import time
+    n = 1 << 16                                              # 64 phases: sampling could take 64 calls
+    pts, sc = co.gen_instance(o.SEED_BASE + 281, n)
+    other = co.gen_instance(o.SEED_BASE + 282, 4)[0]
+    buf = ctypes.create_string_buffer(pts, len(pts))
+    addr = ctypes.cast(buf, ctypes.c_void_p)
+    L = msm_pkg.lib()
+
+    def run():
+        out = ctypes.create_string_buffer(96)
+        ccfg._check(L.msm_amd_gpu_msm_h2c(ccfg.h, sc, addr, n, out))
+        return out.raw
+
+    ccfg.set_bases_cache(64 << 20)
+    ccfg.set_bases_cache_verify(True)
+    base = run()
+    assert _same(base, co.msm_best(sc, pts, n)) and run() == base and ccfg.bases_cache_stats()["hits"] == 1
+    for k, rec in enumerate((37, n - 1, 12345)):             # none of them in phase 0 (multiples of 64)
+        ctypes.memmove(ctypes.addressof(buf) + 64 * rec, other[64 * k:64 * k + 64], 64)
+        got = run()                                          # the FIRST call after the change
+        assert _same(got, co.msm_best(sc, buf.raw, n)), rec
+        assert ccfg.bases_cache_stats()["invalidations"] == k + 1
+        assert run() == got                                  # refilled, hit again
+    # explicit invalidation: sampled mode, a change the sampling would not see at once, the caller says so
+    ccfg.set_bases_cache_verify(False)
+    before = run()
+    ctypes.memmove(ctypes.addressof(buf) + 64 * 41, other[192:256], 64)
+    L.msm_amd_bases_cache_invalidate(ccfg.h, addr)
+    after = run()
+    assert _same(after, co.msm_best(sc, buf.raw, n)) and after != before
+    # what the full check costs (printed with -s; profiles/r04_bases_cache_verify.txt keeps a run)
+    n2 = 1 << 20
+    pts2, sc2 = co.gen_instance(o.SEED_BASE + 283, n2)
+    for full in (False, True):
+        ccfg.set_bases_cache_verify(full)
+        ccfg.msm(sc2, pts2, n2)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ccfg.msm(sc2, pts2, n2)
+        print("bases cache hit, 2^20 points, verify=%s: %.3f ms per blocking call" %
+              ("full" if full else "sampled", (time.perf_counter() - t0) / 5 * 1e3))

@@ -171,6 +171,51 @@ def test_log24_ark_projective_dlog_identity(cfg, msm_pkg):
             cfg.free(d_proj)
 
 
+def test_log24_ark_affine_dlog_identity(cfg, msm_pkg):
+    """BASELINE configs[4], the OTHER arkworks variant SURVEY 8(d) C5 names: 2^24 points as ark_bn254::G1Affine records
+    (72 bytes: x, y, infinity flag + padding; limbs_conversion.rs:132-137 goes through into_group(), which honours the
+    flag), a few of them flagged infinity = 1 with garbage coordinates.  Checked by the dlog identity with the flagged
+    points' terms left out."""
+    import numpy as np
+    n = 1 << 24
+    rng = random.Random(2424)
+    a0, d = rng.randrange(o.R_ORDER), rng.randrange(o.R_ORDER)
+    dp, ds = cfg.generate_instance(o.SEED_BASE + 241, n, True)
+    cfg.free(dp)
+    d_aff = None
+    try:
+        sb = cfg.to_host(ds, 32 * n)
+        pb, _ = co.dlog_instance(a0, d, sb, n)
+        rec = np.zeros((n, 72), dtype=np.uint8)
+        rec[:, :64] = np.frombuffer(pb, dtype=np.uint8).reshape(n, 64)
+        del pb
+        inf = sorted({0, 1, 4097, n // 3, n - 1} | {rng.randrange(n) for _ in range(11)})
+        for i in inf:
+            rec[i, 64] = 1                                        # infinity = true; x, y keep a (now meaningless) point
+            rec[i, 65:72] = 0xAB                                  # padding bytes are not read
+        rec[inf[2], :64] = 0xFF                                   # ... and garbage coordinates under the flag
+        d_aff = cfg.alloc(72 * n)
+        cfg.to_device(d_aff, rec.tobytes())
+        del rec
+        out = cfg.msm_batch_device([ds], [d_aff], [n], point_layout=msm_pkg.POINT_ARK_AFFINE)[0]
+        # expected: the dlog sum without the flagged terms
+        r_inv = pow(o.MONT_R, -1, o.R_ORDER)
+        q = np.frombuffer(sb, dtype="<u2").reshape(n, 16).astype(np.uint64)
+        keep = np.ones(n, dtype=bool)
+        keep[inf] = False
+        idx = np.arange(n, dtype=np.uint64)
+        s0 = [int(x) for x in q[keep].sum(axis=0)]
+        s1 = [int(x) for x in (q[keep] * idx[keep, None]).sum(axis=0)]
+        sum_k = sum(v << (16 * j) for j, v in enumerate(s0))
+        sum_ik = sum(v << (16 * j) for j, v in enumerate(s1))
+        expect = o.scalar_mul((a0 * sum_k + d * sum_ik) * r_inv % o.R_ORDER, o.GEN)
+        assert o.decode_jacobian_mont_le(out) == expect
+    finally:
+        cfg.free(ds)
+        if d_aff is not None:
+            cfg.free(d_aff)
+
+
 def test_log26_resident_dlog_identity(cfg, msm_pkg):
     """Four times configs[4]'s size: 2^26 points (4 GiB of bases, 2 GiB of scalars, device-resident), the call runs as
     8 pipelined point ranges of 2^23.  Checked by the dlog identity; 2^28 points (the largest power of two below the

@@ -119,6 +119,91 @@ def test_rccl_gather_from_cxx_with_the_ranks_this_box_has(cfg, msm_pkg):
         msm_pkg.RcclGather([cfg.device(), cfg.device()])
 
 
+def test_pipelined_multi_context_form_equals_the_blocking_one(cfg, msm_pkg):
+    """msm_amd_submit_batch_multi_device / msm_amd_wait_batch_multi (two batches in flight over two contexts of one
+    device) return the bytes of msm_amd_msm_batch_multi_device; the benchmark loop this keeps fed is
+    benches/msm_benchmark.rs:29-34."""
+    sizes = [1 << 13, 5000, 1 << 12, 33, 1 << 14, 9000, 77]
+    inst = [co.gen_instance(o.SEED_BASE + 80 + j, n) for j, n in enumerate(sizes)]
+    second = msm_pkg.setup_metal_state(cfg.device())
+    ctxs = [cfg, second]
+    dps, dss = [], []
+    try:
+        for j, ((pts, sc), n) in enumerate(zip(inst, sizes)):
+            c = ctxs[msm_pkg.shard_owner(j, 2)]
+            dp, ds = c.alloc(64 * n), c.alloc(32 * n)
+            c.to_device(dp, pts)
+            c.to_device(ds, sc)
+            dps.append(dp)
+            dss.append(ds)
+        blocking = msm_pkg.msm_batch_multi(ctxs, dss, dps, sizes, device=True)
+        assert all(_same(g, co.msm_best(sc, pts, n)) for g, ((pts, sc), n) in zip(blocking, zip(inst, sizes)))
+        h0 = msm_pkg.submit_batch_multi_device(ctxs, dss, dps, sizes)
+        h1 = msm_pkg.submit_batch_multi_device(ctxs, dss[:3], dps[:3], sizes[:3])     # both in flight before any wait
+        assert msm_pkg.wait_batch_multi(h0) == blocking
+        assert msm_pkg.wait_batch_multi(h1) == blocking[:3]
+        one = msm_pkg.submit_batch_multi_device(ctxs, dss[:1], dps[:1], sizes[:1])   # fewer instances than contexts
+        assert msm_pkg.wait_batch_multi(one) == blocking[:1]
+        with pytest.raises(msm_pkg.MsmError):
+            msm_pkg.submit_batch_multi_device([cfg, cfg], dss, dps, sizes)
+    finally:
+        for j, (dp, ds) in enumerate(zip(dps, dss)):
+            ctxs[msm_pkg.shard_owner(j, 2)].free(dp)
+            ctxs[msm_pkg.shard_owner(j, 2)].free(ds)
+        second.close()
+
+
+def test_config4_workload_40_instances_of_2p20_over_eight_contexts(cfg, msm_pkg):
+    """BASELINE config 4's WORKLOAD through the G = 8 code on the one GPU this box has: 40 instances x 2^20 points
+    (one set of dlog-structured bases P_i = (a0 + i d) G shared by all, 40 scalar sets) sharded as instance j ->
+    context j mod 8 over EIGHT contexts of one device -- blocking (msm_amd_msm_batch_multi_device) and pipelined (two
+    batches of 40 in flight) -- then the RCCL gather of the 5 x 96-byte blocks with the ranks the box has.  Every one
+    of the 40 results is checked against (sum k_i (a0 + i d)) G from big integers (tests/helpers.dlog_expected).
+    What this does NOT measure is scaling: eight contexts share one GPU.  The loop being sharded:
+    gpu_profiler.rs:101-106, benches/msm_benchmark.rs:29-34."""
+    from helpers import dlog_expected
+    import random
+    n, inst, G = 1 << 20, 40, 8
+    rng = random.Random(404)
+    a0, d = rng.randrange(o.R_ORDER), rng.randrange(o.R_ORDER)
+    ctxs = [cfg] + [msm_pkg.setup_metal_state(cfg.device()) for _ in range(G - 1)]
+    d_pts, d_sc, want = None, [], []
+    try:
+        for j in range(inst):
+            dp, ds = cfg.generate_instance(o.SEED_BASE + 4000 + j, n, True)   # scalars from the device generator
+            sb = cfg.to_host(ds, 32 * n)
+            if j == 0:
+                pb, _ = co.dlog_instance(a0, d, sb, n)
+                cfg.to_device(dp, pb)
+                d_pts = dp
+            else:
+                cfg.free(dp)
+            d_sc.append(ds)
+            want.append(dlog_expected(a0, d, sb, n))
+        ns = [n] * inst
+        got = msm_pkg.msm_batch_multi(ctxs, d_sc, [d_pts] * inst, ns, device=True)
+        for j in range(inst):
+            assert o.decode_jacobian_mont_le(got[j]) == want[j], j
+        h0 = msm_pkg.submit_batch_multi_device(ctxs, d_sc, [d_pts] * inst, ns)
+        h1 = msm_pkg.submit_batch_multi_device(ctxs, d_sc[::-1], [d_pts] * inst, ns)   # a second batch behind it
+        assert msm_pkg.wait_batch_multi(h0) == got
+        assert msm_pkg.wait_batch_multi(h1) == got[::-1]
+        # the gather of config 4: every rank contributes its ceil(40 / G) x 96 B; this box has one rank
+        g = msm_pkg.RcclGather([cfg.device()])
+        try:
+            mine = b"".join(got[j] for j in range(inst) if msm_pkg.shard_owner(j, G) == 0)
+            assert len(mine) == 5 * 96 and g.all_gather([mine]) == [mine]
+        finally:
+            g.close()
+    finally:
+        for ds in d_sc:
+            cfg.free(ds)
+        if d_pts is not None:
+            cfg.free(d_pts)
+        for c in ctxs[1:]:
+            c.close()
+
+
 def _run(*args):
     r = subprocess.run([EXE, *args, "--json"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
@@ -140,3 +225,12 @@ def test_gpu_profiler_gpus_flag_matches_single_context():
     assert host["results_fnv1a64"] == host1["results_fnv1a64"]
     ranged, _ = _run("14", "5", "gpu", "1", "--devices", "0,0,0", "--range-split")     # every instance over 3 contexts
     assert ranged["results_fnv1a64"] == host1["results_fnv1a64"]
+
+
+def test_gpu_profiler_config4_over_eight_contexts_of_one_device():
+    """`gpu_profiler 20 40 gpu_resident 1 --devices 0,0,0,0,0,0,0,0`: config 4's argv through the sharded CLI path
+    (eight contexts, pipelined submit / wait across retries) gives the results of the single-context run."""
+    single, _ = _run("20", "40", "gpu_resident", "1")
+    eight, err = _run("20", "40", "gpu_resident", "2", "--devices", "0,0,0,0,0,0,0,0")
+    assert eight["results_fnv1a64"] == single["results_fnv1a64"] and eight["gpus"] == 8
+    assert "RCCL gather skipped" in err

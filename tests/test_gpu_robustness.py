@@ -111,11 +111,21 @@ def test_bounded_wait_returns_pipeline_error_and_the_ctx_recovers(msm_pkg):
         dp, ds = cfg.alloc(64 * n), cfg.alloc(32 * n)
         cfg.to_device(dp, pts)
         cfg.to_device(ds, sc)
-        # size every workspace and slot first (lone and pipelined geometry): growing a pinned or device buffer inside
-        # a submit synchronises with the device, i.e. with the hold kernel, and the wait would never be reached
-        assert cfg.msm_batch_device([ds], [dp], [n])[0] == want
-        assert cfg.msm_batch_device([ds] * 8, [dp] * 8, [n] * 8) == [want] * 8
-        assert cfg.msm_batch_device([ds], [dp], [n])[0] == want
+        # nothing is sized in advance (round 4): a call that has to grow a workspace or a page-locked slot behind the
+        # hold kernel waits for the ctx's streams WITH the bound and fails, instead of blocking inside hipMalloc
+        cfg.set_wait_timeout_ms(150)
+        hold0 = cfg.test_hold(4000)
+        t0 = time.perf_counter()
+        with pytest.raises(msm_pkg.MsmError) as e0:
+            cfg.msm_batch_device([ds] * 8, [dp] * 8, [n] * 8)   # first-ever call of this shape: every buffer must grow
+        assert e0.value.status == msm_pkg.PIPELINE_ERROR and "cannot grow" in str(e0.value)
+        assert 0.1 < time.perf_counter() - t0 < 2.0
+        cfg.test_release(hold0)
+        cfg.set_wait_timeout_ms(60000)
+        cfg.synchronize()
+        assert cfg.msm_batch_device([ds] * 8, [dp] * 8, [n] * 8) == [want] * 8   # the ctx recovered; now it is sized
+        for _ in range(4):                                       # ... and so is every workspace for a lone call's geometry
+            assert cfg.msm_batch_device([ds], [dp], [n])[0] == want
         cfg.set_wait_timeout_ms(150)
         hold = cfg.test_hold(4000)
         t0 = time.perf_counter()
