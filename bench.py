@@ -74,6 +74,20 @@ def resolve_world(args, environ):
     return 0, 0, args.gpus, args.gpus > 1
 
 
+KERNEL_SOURCES = ("k_accumulate.hip", "bn254_ec29.hip.h", "bn254_fq29.hip.h", "device_common.hip.h")
+
+
+def kernel_source_digest():
+    """sha256 over the sources of the dominant kernel: profiles/pmc_traffic.json records it (tools/profile_summary.py)
+    and `roofline.traffic` is only replayed from that file while it still matches -- a changed kernel with the old
+    counter figures beside it would be a number from another program."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, PKG, "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -210,9 +224,18 @@ def main(argv=None):
         red_ms.append(t.reduce_ms)
         fin_ms.append(t.final_ms)
 
-    if args.prewarm_steps > 0:                           # clocks up before anything is counted (not warm-up STEPS: the W
-        run_steps(args.prewarm_steps, lambda t: None)    # steps below are still run, the K steps still timed alone)
-    outs = run_steps(args.warmup, lambda t: None)
+    cold_value = None
+    if args.prewarm_steps > 0:
+        # what the plain (W warm-up, K timed) recipe gives on a device whose clocks have not ramped up yet -- reported
+        # beside `value` as `value_without_prewarm` so that a reader comparing by (steps, warmup) sees both
+        run_steps(args.warmup, lambda t: None)
+        barrier()
+        tc0 = time.perf_counter()
+        run_steps(args.steps, lambda t: None)
+        barrier()
+        cold_value = inst * world * args.steps / (time.perf_counter() - tc0)
+        run_steps(args.prewarm_steps, lambda t: None)    # clocks up before anything is counted (not warm-up STEPS: the
+    outs = run_steps(args.warmup, lambda t: None)        # W steps are still run, the K steps still timed alone)
     barrier()
     t0 = time.perf_counter()
     outs = run_steps(args.steps, record)
@@ -245,13 +268,20 @@ def main(argv=None):
     achieved = a3 / (acc_avg_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc_doc = None
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get(f"accumulate_log{args.log_size}_bytes_per_launch")
-            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command, " \
-                          "2*FETCH_SIZE + WRITE_SIZE per launch; not measured by this process)"
+            pmc_doc = json.load(open(tf))
+            if pmc_doc.get("kernel_source_sha256") == kernel_source_digest():
+                traffic = pmc_doc.get(f"accumulate_log{args.log_size}_bytes_per_launch")
+                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command on " \
+                              "this kernel source, 2*FETCH_SIZE + WRITE_SIZE per launch; not measured by this process)"
+            else:
+                pmc_doc = None
+                traffic_src = "refused: profiles/pmc_traffic.json was taken from another version of the kernel source " \
+                              "(kernel_source_sha256 differs) -- re-run tools/profile.sh"
         except Exception:
-            traffic = None
+            traffic, pmc_doc = None, None
     # the kernel's OWN bytes (its window, 4-byte sorted entries, 64-byte packed bases, 144-byte XYZZ buckets)
     own = (4 + 64) * n * tm.num_windows + 144 * tm.num_windows * (1 << max(window - 1, 3))
     roofline = {"bound": "hbm", "kernel": "accumulate_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
@@ -270,9 +300,17 @@ def main(argv=None):
     # 9 x 29-bit limbs) and per affine + affine start of a work item (pti_mmadd, 4M + 2S, incl. the first product of
     # pti_madd that the compiler speculates above the path split) are NOT typed in here: the build disassembles the
     # shipped k_accumulate object and counts them (tools/isa_counts.py -> metal-msm-gpu-acceleration_amd/
-    # isa_counts.json).  Peak: 1.81 wave instructions/ns/CU measured for back-to-back v_mad_u64_u32 at 2 waves/SIMD
-    # (profiles/r01_valu_rates_microbench.txt: one every 5.3 cycles per SIMD, against 3.0 for v_add_u32)
-    # x 256 CUs x 64 lanes = 29.65 T lane-instructions/s.
+    # isa_counts.json).
+    # ONE peak (round 4), measured in shader cycles by the waves themselves (s_memtime; tools/microbench/mul_occ.hip,
+    # profiles/r04_mul_occupancy_microbench.txt, row "straight"): back-to-back independent v_mad_u64_u32 issue every
+    # 4.0 cycles per SIMD at the shipped kernel's occupancy of 2 waves per SIMD (8.0 per wave; 2.0-3.0 per SIMD only
+    # with 8 waves resident, which the mixed addition's ~170 live registers rule out).  x 1024 SIMDs x 64 lanes at the
+    # nominal 2.4 GHz = 39.3 T lane-instructions/s.  A simple instruction (v_add_u32) issues every 2.9 cycles per SIMD
+    # at the same occupancy (profiles/r04_valu_peak_microbench.txt); `valu_issue_utilisation` prices every VALU
+    # instruction of the launch (SQ_INSTS_VALU of profiles/pmc_traffic.json) at those two figures against the SIMD
+    # cycles of the launch.
+    MAD_CYCLES_2W, SIMPLE_CYCLES_2W, SIMDS, CLOCK_HZ = 4.0, 2.9, 1024, 2.4e9
+    peak_mad = SIMDS * 64 * CLOCK_HZ / MAD_CYCLES_2W / 1e12
     isa_path = os.path.join(ROOT, "metal-msm-gpu-acceleration_amd", "isa_counts.json")
     try:
         isa = json.load(open(isa_path))
@@ -283,8 +321,26 @@ def main(argv=None):
     items = float(tm.reserved2[0])
     lane_madds = n * tm.num_windows - 2.0 * items          # first point of an item is free, second is the affine start
     mul_instr = lane_madds * per_madd + items * per_start
+    util = None
+    if pmc_doc is not None and valu_per_madd:
+        try:
+            insts = float(pmc_doc["per_kernel"][next(k for k in pmc_doc["per_kernel"] if k.startswith("accumulate_kernel"))]["SQ_INSTS_VALU"])
+            mult_share = per_madd / float(valu_per_madd)
+            busy = insts * (mult_share * MAD_CYCLES_2W + (1.0 - mult_share) * SIMPLE_CYCLES_2W)
+            util = round(busy / (SIMDS * acc_avg_ms * 1e-3 * CLOCK_HZ), 4)
+        except Exception:   # noqa: BLE001
+            util = None
     valu = {"bound": "valu-int32-multiply", "achieved": round(mul_instr / (acc_avg_ms * 1e-3) / 1e12, 2),
-            "peak": 29.65, "unit": "T lane-instr/s", "frac": round(mul_instr / (acc_avg_ms * 1e-3) / 29.65e12, 4),
+            "peak": round(peak_mad, 2), "unit": "T lane-instr/s",
+            "frac": round(mul_instr / (acc_avg_ms * 1e-3) / (peak_mad * 1e12), 4),
+            "peak_definition": "independent v_mad_u64_u32 back to back at 2 waves/SIMD (the shipped kernel's occupancy): "
+                               "one every 4.0 shader cycles per SIMD, measured in-kernel with s_memtime "
+                               "(profiles/r04_mul_occupancy_microbench.txt) x 1024 SIMDs x 64 lanes x 2.4 GHz",
+            "valu_issue_utilisation": util,
+            "valu_issue_utilisation_definition": "SQ_INSTS_VALU of the launch (profiles/pmc_traffic.json) x (multiplier "
+                                                 "share x 4.0 + rest x 2.9 cycles, the 2-wave issue intervals) / "
+                                                 "(1024 SIMDs x launch time x 2.4 GHz); null when the counter file "
+                                                 "is not of this kernel source",
             "work_items": int(items),
             "multiplier_instructions_per_mixed_addition": int(per_madd),
             "multiplier_instructions_per_affine_start": int(per_start),
@@ -317,7 +373,28 @@ def main(argv=None):
             for j in range(inst):          # parity gate: bit-exact canonical affine result
                 if o.decode_jacobian_mont_le(outs[j]) != o.decode_jacobian_mont_le(cpu_outs[j]):
                     raise SystemExit(f"PARITY FAILURE: instance {j} GPU != CPU")
+            # the product's own CPU MSM (msm_amd_host_msm: what `gpu_profiler .. cpu` and msm_best's CPU side run) on the
+            # same instances and threads, next to the restatement of the reference's CPU path
+            t_p0 = time.perf_counter()
+            p_done = 0
+            while True:
+                for j in range(inst):
+                    pr = m.host_msm(h_sc[j], h_pts[j], n, threads=cores)
+                    if p_done < inst and o.decode_jacobian_mont_le(pr) != o.decode_jacobian_mont_le(cpu_outs[j]):
+                        raise SystemExit(f"PARITY FAILURE: instance {j} product CPU MSM != oracle")
+                    p_done += 1
+                if time.perf_counter() - t_p0 > args.cpu_seconds / 4 or p_done >= 8 * inst:
+                    break
+            t_prod = time.perf_counter() - t_p0
+            gpu_rate = inst * world * args.steps / elapsed
             cpu = {"value": round(done / t_cpu, 4), "unit": "MSM/s", "cores": cores, "cpu_model": cpu_model(),
+                   "product_cpu_msm": {"value": round(p_done / t_prod, 4), "unit": "MSM/s", "cores": cores,
+                                       "kind": "msm_amd_host_msm (this library's batched-affine Pippenger, AVX-512 "
+                                               "IFMA where the host has it): faster than the restatement, NOT the "
+                                               "reference's CPU path",
+                                       "sample": f"{p_done} MSMs in {t_prod:.1f} s", "bit_exact_vs_oracle": True},
+                   "gpu_over_cpu": {"vs_reference_restatement": round(gpu_rate / (done / t_cpu), 1),
+                                    "vs_product_cpu_msm": round(gpu_rate / (p_done / t_prod), 1)},
                    "logical_cpus_visible": len(os.sched_getaffinity(0)),
                    "kind": "port", "algorithm": co.MSM_BEST_ALGORITHM, "shape": cpu_info,
                    "sample": f"{done} MSMs of 2^{args.log_size} points (the bench's own {inst} instances, "
@@ -346,6 +423,7 @@ def main(argv=None):
             "steps": args.steps,
             "warmup": args.warmup,
             "device_prewarm_steps": args.prewarm_steps,   # untimed load before the warm-up steps (GPU clock ramp), see --help
+            "value_without_prewarm": None if cold_value is None else round(cold_value, 3),   # same W, same K, cold clocks
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",

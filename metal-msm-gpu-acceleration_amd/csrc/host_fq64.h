@@ -8,6 +8,7 @@
 // so u256 / Jacobian records are reinterpreted in place (little-endian hosts only, checked below).
 // Replaces the arithmetic under final_accumulation.rs:19-39 (host-side window Horner of the reference).
 #pragma once
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 
@@ -127,12 +128,14 @@ inline Fe mul_portable(const Fe& a, const Fe& b) {
 }
 #undef MSM_H64_ROUND
 
-#if defined(__x86_64__) && defined(__BMI2__) && defined(__ADX__) && !defined(MSM_H64_NO_ASM)
+#if defined(__x86_64__) && !defined(MSM_H64_NO_ASM)
 // The same CIOS rounds with MULX and the two independent carry chains of ADCX (CF) / ADOX (OF): the low halves of
 // a_j * b_i ride one chain, the high halves the other, so no carry is ever materialised in a register.  The
 // running value lives in five registers whose roles rotate from round to round (the word that the reduction zeroes
-// becomes the next round's top word).  ~1.45x the rate of the portable form above on Zen 5 / Sapphire Rapids;
-// built only where the compiler is told the host has BMI2 + ADX (csrc/Makefile: HOST64_FLAGS).
+// becomes the next round's top word).  ~1.45x the rate of the portable form above on Zen 5 / Sapphire Rapids.
+// Only this ONE function is compiled for BMI2 + ADX (target attribute, no -m flags on the translation unit: the
+// compiler must not use either extension anywhere else), and mul() asks CPUID once before using it -- the library
+// loads and runs on an x86-64 host without them (the portable form), like the AVX-512 IFMA path of host_ifma.cpp.
 #define MSM_H64_ASM_ROUND(i, T0, T1, T2, T3, T4)                                                    \
   "movq " #i "*8(%[b]), %%rdx\n\t"                                                                  \
   "xorl %k[" #T4 "], %k[" #T4 "]\n\t" /* top word = 0; clears CF and OF */                           \
@@ -148,7 +151,7 @@ inline Fe mul_portable(const Fe& a, const Fe& b) {
   "mulx 16(%[p]), %[lo], %[hi]\n\t adcx %[lo], %[" #T2 "]\n\t  adox %[hi], %[" #T3 "]\n\t"          \
   "mulx 24(%[p]), %[lo], %[hi]\n\t adcx %[lo], %[" #T3 "]\n\t  adox %[hi], %[" #T4 "]\n\t"          \
   "movl $0, %k[lo]\n\t             adcx %[lo], %[" #T4 "]\n\t"
-inline Fe mul(const Fe& a, const Fe& b) {
+__attribute__((target("bmi2,adx"))) inline Fe mul_mulx(const Fe& a, const Fe& b) {
   static const uint64_t kP[4] = {P[0], P[1], P[2], P[3]};
   uint64_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, lo, hi;
   __asm__(MSM_H64_ASM_ROUND(0, r0, r1, r2, r3, r4)   /* leaves the value in r1 r2 r3 r4 (r0 = 0) */
@@ -167,6 +170,17 @@ inline Fe mul(const Fe& a, const Fe& b) {
   return r;
 }
 #undef MSM_H64_ASM_ROUND
+inline bool have_mulx_adx() {   // CPUID.(EAX=7,ECX=0):EBX bit 8 = BMI2, bit 19 = ADX
+  static const bool ok = [] {
+    unsigned a = 0, b = 0, c = 0, d = 0;
+    __asm__("cpuid" : "=a"(a), "=b"(b), "=c"(c), "=d"(d) : "a"(0), "c"(0));
+    if (a < 7) return false;
+    __asm__("cpuid" : "=a"(a), "=b"(b), "=c"(c), "=d"(d) : "a"(7), "c"(0));
+    return ((b >> 8) & 1u) && ((b >> 19) & 1u) && !std::getenv("MSM_AMD_HOST_NO_MULX");
+  }();
+  return ok;
+}
+inline Fe mul(const Fe& a, const Fe& b) { return have_mulx_adx() ? mul_mulx(a, b) : mul_portable(a, b); }
 #else
 inline Fe mul(const Fe& a, const Fe& b) { return mul_portable(a, b); }
 #endif

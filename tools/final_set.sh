@@ -8,8 +8,10 @@ set -u
 tag=${1:-final}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
+# the counter passes first: bench.py replays roofline.traffic from profiles/pmc_traffic.json only while that file
+# belongs to the kernel source it runs (kernel_source_sha256), so the file is refreshed before the evidence line is taken
+bash tools/profile.sh $tag && cp gpurun_out/prof_$tag/summary/${tag}_pmc.json profiles/pmc_traffic.json && \
 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err && echo "bench ok" && \
-bash tools/profile.sh $tag && \
 { cd $R/metal-msm-gpu-acceleration_amd
   ./gpu_profiler 24 1 gpu_resident 5 --layout ark --warmup 4 --json 2>/dev/null | grep '^{'
   ./gpu_profiler 18 1 gpu_resident 30 --warmup 4 --json 2>/dev/null | grep '^{'

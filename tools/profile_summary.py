@@ -86,5 +86,9 @@ if pmc:
                "per_kernel": pmc}
     if a and "FETCH_SIZE" in a and "WRITE_SIZE" in a:
         summary["accumulate_log20_bytes_per_launch"] = int((2 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024)
+    # which kernel source these counters belong to: bench.py refuses roofline.traffic when the files have changed since
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    summary["kernel_source_sha256"] = bench.kernel_source_digest()
     json.dump(summary, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 print("summary files:", sorted(os.listdir(dst)))
