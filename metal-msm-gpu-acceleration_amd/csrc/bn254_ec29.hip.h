@@ -159,10 +159,10 @@ MSM_HD PtI pti_double(const PtI& p) {   // p not the identity
 // MSM_FQ29_LOCKSTEP: the independent products of the formula run side by side as lockstep product-scanning chains
 // (Fq29::fips_multi): (U2, S2), (PP, RR), (PPP, Q, ZZ3), (Y3, ZZZ3).
 MSM_HD PtI pti_madd(const PtI& p, const AffI& q, bool& vanished) {
-#if defined(MSM_FQ29_LOCKSTEP)
+#if defined(MSM_AMD_EXPERIMENTS) && defined(MSM_FQ29_LOCKSTEP)
   fe29 U2, S2;
   Fq29::mul_pair(q.x, p.zz, q.y, p.zzz, U2, S2);
-#elif defined(MSM_FQ29_KARATSUBA)
+#elif defined(MSM_AMD_EXPERIMENTS) && defined(MSM_FQ29_KARATSUBA)
   const fe29 U2 = Fq29::mul_karatsuba(q.x, p.zz);
   const fe29 S2 = Fq29::mul_karatsuba(q.y, p.zzz);
 #else
@@ -181,14 +181,14 @@ MSM_HD PtI pti_madd(const PtI& p, const AffI& q, bool& vanished) {
   }
   MSM_ISA_MARK("resume mixed_addition");
   PtI r;
-#if defined(MSM_FQ29_LOCKSTEP)
+#if defined(MSM_AMD_EXPERIMENTS) && defined(MSM_FQ29_LOCKSTEP)
   fe29 PP, RR, PPP, Q;
   Fq29::sqr_pair(P, R, PP, RR);
   Fq29::mul_triple(P, PP, p.x, PP, p.zz, PP, PPP, Q, r.zz);
   r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.5 p
   const fe29 T = Fq29::sub<K16E30>(Q, r.x);                                               // < 17.2 p
   Fq29::mul2_mul_pair(R, T, p.y, Fq29::neg_wide(PPP), p.zzz, PPP, r.y, r.zzz);
-#elif defined(MSM_FQ29_KARATSUBA)
+#elif defined(MSM_AMD_EXPERIMENTS) && defined(MSM_FQ29_KARATSUBA)
   const fe29 PP = Fq29::sqr(P);
   const fe29 PPP = Fq29::mul_karatsuba(P, PP);
   const fe29 Q = Fq29::mul_karatsuba(p.x, PP);
@@ -244,131 +244,11 @@ MSM_HD PtI pti_mmadd(const fe29& px, const fe29& py, const AffI& q, bool& vanish
 }
 
 
-// ---- register-lean forms (accumulate_kernel_lean: at most 128 VGPRs, 4 waves per SIMD) ------------------------------
-// The same operations on the same values as pti_madd / pti_mmadd (so tools/fq29_bounds.py covers them), but
-//   * every product is ONE product-scanning chain (Fq29::fips: a single 64-bit running column, 9 quotient digits)
-//     instead of 17 live 64-bit column sums;
-//   * the products are ordered so that an input dies as soon as its last product is done (ZZ1 * PP before X1 * PP
-//     before P * PP ...), the accumulator is updated IN PLACE, and a scheduling barrier between products stops the
-//     compiler from overlapping them again (at 4 waves per SIMD the other waves supply the independent work).
-// Peak: 4 x 9 accumulator + 3 x 9 temporaries + 9 doubled limbs + chain state (9 + 2 + 9) = 92 registers.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define MSM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define MSM_SCHED_FENCE() ((void)0)
+// The register-lean (product-scanning) and LDS-parked forms of the mixed addition behind the experimental accumulate
+// kernels: experiments/ec29_variants.inc, -DMSM_AMD_EXPERIMENTS builds only.
+#if defined(MSM_AMD_EXPERIMENTS)
+#include "experiments/ec29_variants.inc"
 #endif
-MSM_HD fe29 fips_mul(const fe29& a, const fe29& b) {
-  const fe29* const xs[1] = {&a};
-  const fe29* const ys[1] = {&b};
-  return Fq29::fips<1>(xs, ys);
-}
-MSM_HD fe29 fips_sqr(const fe29& a) {
-  fe29 d2;
-  MSM_UNROLL for (int i = 0; i < 9; ++i) d2.l[i] = a.l[i] << 1;
-  const fe29* const xs[1] = {&d2};
-  const fe29* const ys[1] = {&a};
-  return Fq29::fips<1, true>(xs, ys);
-}
-MSM_HD fe29 fips_mul2(const fe29& a, const fe29& b, const fe29& c, const fe29& d) {
-  const fe29* const xs[2] = {&a, &c};
-  const fe29* const ys[2] = {&b, &d};
-  return Fq29::fips<2>(xs, ys);
-}
-// Shared tail of the two lean additions: acc = (X1, Y1, ZZ1, ZZZ1), P, R given; AFFINE accumulators skip ZZ1 / ZZZ1.
-// `midway` runs once the temporaries of the first half are dead (the accumulate kernel issues the gather of the next
-// base there: 16 registers that would not fit any earlier).
-template <bool AFFINE_ACC, class Midway>
-MSM_HD void pti_lean_tail(PtI& acc, fe29& P, const fe29& R, const Midway& midway) {
-  fe29 PP = fips_sqr(P);
-  MSM_SCHED_FENCE();
-  if (AFFINE_ACC) acc.zz = PP; else acc.zz = fips_mul(acc.zz, PP);
-  MSM_SCHED_FENCE();
-  fe29 Q = fips_mul(acc.x, PP);                      // X1 dies here
-  MSM_SCHED_FENCE();
-  P = fips_mul(P, PP);                               // P becomes PPP; PP dies here
-  MSM_SCHED_FENCE();
-  midway();
-  MSM_SCHED_FENCE();
-  if (AFFINE_ACC) acc.zzz = P; else acc.zzz = fips_mul(acc.zzz, P);
-  MSM_SCHED_FENCE();
-  acc.x = fips_sqr(R);                               // RR
-  acc.x = Fq29::norm(Fq29::sub<K8E31>(acc.x, Fq29::add(P, Fq29::add(Q, Q))));
-  Q = Fq29::sub<K16E30>(Q, acc.x);                   // T, un-normalised like pti_madd's
-  if (AFFINE_ACC) Q = Fq29::norm(Q);                 // pti_mmadd normalises T (its R is wider)
-  P = Fq29::neg_wide(P);
-  MSM_SCHED_FENCE();
-  acc.y = fips_mul2(R, Q, acc.y, P);                 // R*T - Y1*PPP
-}
-// acc += q in place; acc XYZZ (not the identity), q affine (not the identity).  Returns false when the sum vanished
-// (acc is then unspecified: the caller tracks the state).
-// Rare-path helpers on product-scanning chains (the column form of Fq29::mul keeps 17 64-bit sums live and would set
-// the register count of the whole kernel).
-MSM_HD bool is_zero_exact_lean(const fe29& a) {
-  const fe29 o = Fq29::one();
-  return Fq29::is_zero_limbs(Fq29::canonical(fips_mul(a, o), 1));
-}
-MSM_HD PtI pti_double_lean(const PtI& p) {   // pti_double, operation for operation
-  const fe29 U = Fq29::add(p.y, p.y);
-  const fe29 V = fips_sqr(U);
-  const fe29 W = fips_mul(U, V);
-  const fe29 S = fips_mul(p.x, V);
-  const fe29 XX = fips_sqr(p.x);
-  const fe29 M = Fq29::norm(Fq29::add(XX, Fq29::add(XX, XX)));
-  const fe29 MM = fips_sqr(M);
-  PtI r;
-  r.x = Fq29::norm(Fq29::sub<K4E30>(MM, Fq29::add(S, S)));
-  const fe29 T = Fq29::norm(Fq29::sub<K8E30>(S, r.x));
-  r.y = Fq29::norm(Fq29::sub<K4E30>(fips_mul(M, T), fips_mul(W, p.y)));
-  r.zz = fips_mul(V, p.zz);
-  r.zzz = fips_mul(W, p.zzz);
-  return r;
-}
-// `again` fetches q once more for the rare doubling (q == acc), so that q.x and q.y die with their first product.
-template <class Refetch, class Midway>
-MSM_HD bool pti_madd_lean(PtI& acc, const AffI& q, const Refetch& again, const Midway& midway) {
-  fe29 P = fips_mul(q.x, acc.zz);
-  P = Fq29::norm(Fq29::sub<K16E30>(P, acc.x));
-  MSM_SCHED_FENCE();
-  fe29 R = fips_mul(q.y, acc.zzz);
-  R = Fq29::norm(Fq29::sub<K8E30>(R, acc.y));
-  MSM_SCHED_FENCE();
-  if (Fq29::maybe_zero(P, 18)) {
-    MSM_ISA_MARK("rare mixed_addition");
-    if (is_zero_exact_lean(P)) {
-      if (is_zero_exact_lean(R)) {
-        acc = pti_double_lean(pti_from_affi(again()));
-        midway();
-        return true;
-      }
-      midway();
-      return false;
-    }
-  }
-  MSM_ISA_MARK("resume mixed_addition");
-  pti_lean_tail<false>(acc, P, R, midway);
-  return true;
-}
-// The same for an accumulator that still holds ONE affine base (acc.x, acc.y; ZZ = ZZZ = 1).
-template <class Refetch, class Midway>
-MSM_HD bool pti_mmadd_lean(PtI& acc, const AffI& q, const Refetch& again, const Midway& midway) {
-  fe29 P = Fq29::norm(Fq29::sub<K16E30>(q.x, acc.x));
-  fe29 R = Fq29::norm(Fq29::sub<K8E30>(q.y, acc.y));
-  if (Fq29::maybe_zero(P, 18)) {
-    MSM_ISA_MARK("rare affine_start");
-    if (is_zero_exact_lean(P)) {
-      if (is_zero_exact_lean(R)) {
-        acc = pti_double_lean(pti_from_affi(again()));
-        midway();
-        return true;
-      }
-      midway();
-      return false;
-    }
-  }
-  MSM_ISA_MARK("resume affine_start");
-  pti_lean_tail<true>(acc, P, R, midway);
-  return true;
-}
 
 MSM_HD PtI pti_madd(const PtI& p, const AffI& q) {
   bool vanished = false;

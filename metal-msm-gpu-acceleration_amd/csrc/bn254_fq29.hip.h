@@ -168,159 +168,17 @@ struct Fq29 {
   }
 
 
-  // ---- product-scanning ("FIPS") forms: one running 64-bit accumulator per column, whose chain STARTS from the
-  // carry of the column below (the free 64-bit addend of the first v_mad_u64_u32), so no 64-bit additions are
-  // needed to propagate carries, and no 17 column sums are live at once.  Same values as mul / sqr / mul2.  The
-  // multiply-adds are written as inline assembly because LLVM re-associates a chain of 64-bit additions back
-  // into independent partial sums plus 64-bit adds.
-  MSM_HD static void mad64(uint64_t& t, uint32_t x, uint32_t y) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint64_t co;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(t), "=s"(co) : "v"(x), "v"(y));
-#else
-    t += (uint64_t)x * y;
+  // The multiplication forms that were built, measured and NOT shipped (product scanning, lockstep chains, one
+  // Karatsuba level: DESIGN.md / HISTORY.md) live in experiments/fq29_variants.inc; they are members of this struct only
+  // in -DMSM_AMD_EXPERIMENTS builds (tools/build_variant.sh exp, the microbenchmarks, tests/test_gpu_experiments.py).
+#if defined(MSM_AMD_EXPERIMENTS)
+#include "experiments/fq29_variants.inc"
 #endif
-  }
-  MSM_HD static void mad64c(uint64_t& t, uint32_t x, uint32_t c) {   // c: a constant limb of p (scalar register)
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint64_t co;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(t), "=s"(co) : "v"(x), "s"(c));
-#else
-    t += (uint64_t)x * c;
-#endif
-  }
-  // SQUARE: one product, x = 2a (doubled limbs), y = a: cross products i < j only, plus a_(k/2)^2 in even columns
-  template <int NPROD, bool SQUARE = false>
-  MSM_HD static fe29 fips(const fe29* const (&x)[NPROD], const fe29* const (&y)[NPROD]) {
-    uint32_t m[9];
-    fe29 r;
-    uint64_t t = 0;
-    MSM_UNROLL for (int k = 0; k < 17; ++k) {
-      MSM_UNROLL for (int q = 0; q < NPROD; ++q) {
-        MSM_UNROLL for (int i = 0; i < 9; ++i) {
-          const int j = k - i;
-          if (j >= 0 && j < 9 && (!SQUARE || i < j)) mad64(t, x[q]->l[i], y[q]->l[j]);
-        }
-        if (SQUARE && (k & 1) == 0) mad64(t, y[q]->l[k >> 1], y[q]->l[k >> 1]);
-      }
-      MSM_UNROLL for (int i = 0; i < 9; ++i) {
-        const int j = k - i;
-        if (i < k && j >= 1 && j < 9) mad64c(t, m[i], p(j));
-      }
-      if (k < 9) {
-        m[k] = ((uint32_t)t * INV) & MASK;
-        mad64c(t, m[k], p(0));
-      } else {
-        r.l[k - 9] = (uint32_t)t & MASK;
-      }
-      t >>= 29;
-    }
-    r.l[8] = (uint32_t)t;
-    return r;
-  }
-
-  // Two (or three) INDEPENDENT products in lockstep, product-scanning form: column k of every job is accumulated
-  // before column k + 1 of any, with the multiply-adds of the jobs alternating instruction by instruction.  One
-  // product-scanning chain is a string of dependent v_mad_u64_u32 (8.5 cycles from one to the next when a wave is
-  // alone: fq29_bench, 1741 cycles per multiplication at 1 wave/SIMD against 1107 at 4); two chains per wave and two
-  // waves per SIMD give the issue logic four independent streams -- what fips<> alone only gets at 4 waves/SIMD,
-  // which the accumulate kernel cannot have.  Against the column-parallel mul() this saves the 64-bit carry addition
-  // of every column (the chain starts FROM the carry) and the 17 x 2 live column registers.
-  // Job q: value = sum over its NPROD products x[q][r] * y[q][r]; SQUARE jobs pass x = 2a, y = a.
-  struct FipsJob {
-    const fe29* x[2];
-    const fe29* y[2];
-  };
-  template <int NJOBS, int NP0, bool SQ0, int NP1, bool SQ1, int NP2 = 0, bool SQ2 = false>
-  MSM_HD static void fips_multi(const FipsJob (&job)[NJOBS], fe29 (&r)[NJOBS]) {
-    constexpr int np[3] = {NP0, NP1, NP2};
-    constexpr bool sq[3] = {SQ0, SQ1, SQ2};
-    uint32_t m[NJOBS][9];
-    uint64_t t[NJOBS];
-    MSM_UNROLL for (int q = 0; q < NJOBS; ++q) t[q] = 0;
-    MSM_UNROLL for (int k = 0; k < 17; ++k) {
-      MSM_UNROLL for (int i = 0; i < 9; ++i) {
-        const int j = k - i;
-        MSM_UNROLL for (int q = 0; q < NJOBS; ++q) {
-          MSM_UNROLL for (int pr = 0; pr < 2; ++pr) {
-            if (pr < np[q] && j >= 0 && j < 9 && (!sq[q] || i < j)) mad64(t[q], job[q].x[pr]->l[i], job[q].y[pr]->l[j]);
-          }
-        }
-      }
-      MSM_UNROLL for (int q = 0; q < NJOBS; ++q) {
-        MSM_UNROLL for (int pr = 0; pr < 2; ++pr) {
-          if (pr < np[q] && sq[q] && (k & 1) == 0) mad64(t[q], job[q].y[pr]->l[k >> 1], job[q].y[pr]->l[k >> 1]);
-        }
-      }
-      MSM_UNROLL for (int i = 0; i < 9; ++i) {
-        const int j = k - i;
-        MSM_UNROLL for (int q = 0; q < NJOBS; ++q) {
-          if (i < k && j >= 1 && j < 9) mad64c(t[q], m[q][i], p(j));
-        }
-      }
-      MSM_UNROLL for (int q = 0; q < NJOBS; ++q) {
-        if (k < 9) {
-          m[q][k] = ((uint32_t)t[q] * INV) & MASK;
-          mad64c(t[q], m[q][k], p(0));
-        } else {
-          r[q].l[k - 9] = (uint32_t)t[q] & MASK;
-        }
-        t[q] >>= 29;
-      }
-    }
-    MSM_UNROLL for (int q = 0; q < NJOBS; ++q) r[q].l[8] = (uint32_t)t[q];
-  }
-  // (a * b, c * d) -- two multiplications side by side
-  MSM_HD static void mul_pair(const fe29& a_in, const fe29& b_in, const fe29& c_in, const fe29& d_in, fe29& ab, fe29& cd) {
-    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in), c = pin_limbs(c_in), d = pin_limbs(d_in);
-    const FipsJob jobs[2] = {{{&a, nullptr}, {&b, nullptr}}, {{&c, nullptr}, {&d, nullptr}}};
-    fe29 r[2];
-    fips_multi<2, 1, false, 1, false>(jobs, r);
-    ab = r[0];
-    cd = r[1];
-  }
-  // (a^2, b^2)
-  MSM_HD static void sqr_pair(const fe29& a_in, const fe29& b_in, fe29& aa, fe29& bb) {
-    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in);
-    fe29 a2, b2;
-    MSM_UNROLL for (int i = 0; i < 9; ++i) {
-      a2.l[i] = a.l[i] << 1;
-      b2.l[i] = b.l[i] << 1;
-    }
-    const FipsJob jobs[2] = {{{&a2, nullptr}, {&a, nullptr}}, {{&b2, nullptr}, {&b, nullptr}}};
-    fe29 r[2];
-    fips_multi<2, 1, true, 1, true>(jobs, r);
-    aa = r[0];
-    bb = r[1];
-  }
-  // (a * b + c * d, e * f) -- the shared-reduction double product next to a plain multiplication
-  MSM_HD static void mul2_mul_pair(const fe29& a_in, const fe29& b_in, const fe29& c_in, const fe29& d_in, const fe29& e_in,
-                                   const fe29& f_in, fe29& abcd, fe29& ef) {
-    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in), c = pin_limbs(c_in), d = pin_limbs(d_in), e = pin_limbs(e_in),
-               f = pin_limbs(f_in);
-    const FipsJob jobs[2] = {{{&a, &c}, {&b, &d}}, {{&e, nullptr}, {&f, nullptr}}};
-    fe29 r[2];
-    fips_multi<2, 2, false, 1, false>(jobs, r);
-    abcd = r[0];
-    ef = r[1];
-  }
-  // (a * b, c * d, e * f) -- three multiplications side by side
-  MSM_HD static void mul_triple(const fe29& a_in, const fe29& b_in, const fe29& c_in, const fe29& d_in, const fe29& e_in,
-                                const fe29& f_in, fe29& ab, fe29& cd, fe29& ef) {
-    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in), c = pin_limbs(c_in), d = pin_limbs(d_in), e = pin_limbs(e_in),
-               f = pin_limbs(f_in);
-    const FipsJob jobs[3] = {{{&a, nullptr}, {&b, nullptr}}, {{&c, nullptr}, {&d, nullptr}}, {{&e, nullptr}, {&f, nullptr}}};
-    fe29 r[3];
-    fips_multi<3, 1, false, 1, false, 1, false>(jobs, r);
-    ab = r[0];
-    cd = r[1];
-    ef = r[2];
-  }
 
   // a*b*rho^-1 mod p (lazily reduced).  81 + 81 limb products, no carry instructions.
   MSM_HD static fe29 mul(const fe29& a_in, const fe29& b_in) {
     const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in);
-#if defined(MSM_FQ29_FIPS)
+#if defined(MSM_AMD_EXPERIMENTS) && defined(MSM_FQ29_FIPS)
     {
       const fe29* const xs[1] = {&a};
       const fe29* const ys[1] = {&b};
@@ -339,77 +197,12 @@ struct Fq29 {
     return reduce_columns(A);
   }
 
-  // One Karatsuba level over 3-limb blocks (a = A0 + A1 B + A2 B^2, B = 2^87): six 3 x 3 block products (54
-  // multiply-adds) instead of nine (81), paid for with 18 limb additions and 30 64-bit column subtractions
-  //   A0B0, A1B1, A2B2,  (A0+A1)(B0+B1) - A0B0 - A1B1,  (A0+A2)(B0+B2) - A0B0 - A2B2,  (A1+A2)(B1+B2) - A1B1 - A2B2
-  // Every column of a bracketed product dominates the same column of what is subtracted from it (the difference is
-  // the column of the cross terms), so the subtractions never borrow.  Operands must be normalised (limbs <= 2^29 + 8:
-  // a block sum then stays below 2^30 + 16 and a 3-term column below 2^62).
-  MSM_HD static void karatsuba_columns(const fe29& a, const fe29& b, uint64_t (&A)[17]) {
-    uint64_t P[3][5];   // A_i * B_i
-    MSM_UNROLL for (int blk = 0; blk < 3; ++blk) {
-      MSM_UNROLL for (int c = 0; c < 5; ++c) {
-        uint64_t s = 0;
-        MSM_UNROLL for (int i = 0; i < 3; ++i) {
-          const int j = c - i;
-          if (j >= 0 && j < 3) s += (uint64_t)a.l[3 * blk + i] * b.l[3 * blk + j];
-        }
-        P[blk][c] = s;
-      }
-    }
-    MSM_UNROLL for (int c = 0; c < 5; ++c) {   // A is ACCUMULATED into: the caller zeroes it or has another product there
-      A[c] += P[0][c];
-      A[12 + c] += P[2][c];
-    }
-    // cross terms of blocks (x, y) land at columns 3 (x + y) ..; the middle one starts from A1B1's columns
-    MSM_UNROLL for (int pr = 0; pr < 3; ++pr) {
-      const int x = pr == 2 ? 1 : 0, y = pr == 0 ? 1 : 2;
-      uint32_t sa[3], sb[3];
-      MSM_UNROLL for (int i = 0; i < 3; ++i) {
-        sa[i] = limb32(a.l[3 * x + i] + a.l[3 * y + i]);
-        sb[i] = limb32(b.l[3 * x + i] + b.l[3 * y + i]);
-      }
-      MSM_UNROLL for (int c = 0; c < 5; ++c) {
-        uint64_t s = (pr == 1) ? P[1][c] : 0;
-        MSM_UNROLL for (int i = 0; i < 3; ++i) {
-          const int j = c - i;
-          if (j >= 0 && j < 3) s += (uint64_t)sa[i] * sb[j];
-        }
-        s -= P[x][c];
-        s -= P[y][c];
-        A[3 * (x + y) + c] += s;
-      }
-    }
-  }
-  MSM_HD static fe29 mul_karatsuba(const fe29& a_in, const fe29& b_in) {
-    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in);
-    uint64_t A[17];
-    MSM_UNROLL for (int k = 0; k < 17; ++k) A[k] = 0;
-    karatsuba_columns(a, b, A);
-    return reduce_columns(A);
-  }
-  // a * b (schoolbook: b may be an un-normalised difference with limbs < 2^31) + c * d (Karatsuba), one reduction
-  MSM_HD static fe29 mul2_karatsuba_second(const fe29& a_in, const fe29& b_in, const fe29& c_in, const fe29& d_in) {
-    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in), c = pin_limbs(c_in), d = pin_limbs(d_in);
-    uint64_t A[17];
-    MSM_UNROLL for (int k = 0; k < 17; ++k) {
-      uint64_t s = 0;
-      MSM_UNROLL for (int i = 0; i < 9; ++i) {
-        const int j = k - i;
-        if (j >= 0 && j < 9) s += (uint64_t)a.l[i] * b.l[j];
-      }
-      A[k] = s;
-    }
-    karatsuba_columns(c, d, A);
-    return reduce_columns(A);
-  }
-
   // (a*b + c*d)*rho^-1 with ONE Montgomery reduction: 81 + 81 + 81 limb products instead of 2 x (81 + 81).
   // All four operands must be normalised (limbs <= 2^29 + 8) so that a column of 18 + 9 products stays
   // below 2^64.  Used for Y3 = R*T - Y1*PPP with d = -PPP.
   MSM_HD static fe29 mul2(const fe29& a_in, const fe29& b_in, const fe29& c_in, const fe29& d_in) {
     const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in), c = pin_limbs(c_in), d = pin_limbs(d_in);
-#if defined(MSM_FQ29_FIPS)
+#if defined(MSM_AMD_EXPERIMENTS) && defined(MSM_FQ29_FIPS)
     {
       const fe29* const xs[2] = {&a, &c};
       const fe29* const ys[2] = {&b, &d};
@@ -434,7 +227,7 @@ struct Fq29 {
   // a*a*rho^-1: 45 + 81 limb products (cross products use the doubled operand).
   MSM_HD static fe29 sqr(const fe29& a_in) {
     const fe29 a = pin_limbs(a_in);
-#if defined(MSM_FQ29_FIPS)
+#if defined(MSM_AMD_EXPERIMENTS) && defined(MSM_FQ29_FIPS)
     {
       fe29 d2;
       MSM_UNROLL for (int i = 0; i < 9; ++i) d2.l[i] = a.l[i] << 1;

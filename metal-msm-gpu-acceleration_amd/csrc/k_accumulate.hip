@@ -21,7 +21,7 @@ namespace msm_amd {
 // PIN: touch v175 so that the kernel allocates 176 VGPRs and runs at two waves per SIMD whatever it needs itself.
 template <bool PREFETCH, bool PIN, int WHATIF = 0>
 __device__ __forceinline__ void
-accumulate_body(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,
+accumulate_item(const uint32_t slot, const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,
                 const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
                 const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
                 const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
@@ -31,7 +31,6 @@ accumulate_body(const AffPacked* __restrict__ bases, const uint32_t* __restrict_
   // on a 1 MB slice of the bases (every gather hits the L2)
   constexpr uint32_t IDX_MASK = WHATIF == 2 ? 0x3FFFu : 0x7FFFFFFFu;
   if (PIN) asm volatile("v_mov_b32 v175, 0" ::: "v175");
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= counters->total_items) return;
   const uint2 it = order[slot];
   const uint32_t b = it.x, j = it.y;
@@ -115,6 +114,17 @@ accumulate_body(const AffPacked* __restrict__ bases, const uint32_t* __restrict_
   }
 }
 
+template <bool PREFETCH, bool PIN, int WHATIF = 0>
+__device__ __forceinline__ void
+accumulate_body(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
+                const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
+                const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
+                uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
+  accumulate_item<PREFETCH, PIN, WHATIF>(blockIdx.x * blockDim.x + threadIdx.x, bases, sorted, bucket_start, bucket_size,
+                                         item_start, win_base, order, counters, n, lb, CH, buckets, partials);
+}
+
 #define MSM_ACC_PARAMS const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,                       \
                        const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,           \
                        const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,                \
@@ -127,96 +137,14 @@ template <bool LOW_OCC>
 __global__ void __launch_bounds__(64) accumulate_kernel(MSM_ACC_PARAMS) {
   accumulate_body<LOW_OCC, LOW_OCC>(MSM_ACC_FWD);
 }
+// Other builds of this kernel -- three waves per SIMD, the register-lean product-scanning form at four, the compiler's
+// column form at four with Y / ZZ / ZZZ parked in LDS, the hand-allocated five-wave statement of
+// tools/gen_accumulate_asm.py, and the what-if timing kernels -- were built, checked bit for bit and measured in round
+// 4 (profiles/r04_ab_accumulate_occupancy.txt); none is faster than the kernel above, so they only exist in
+// -DMSM_AMD_EXPERIMENTS builds (MSM_AMD_ACC_VARIANT selects one there).
 #if defined(MSM_AMD_EXPERIMENTS)
-__global__ void __launch_bounds__(64) accumulate_whatif_gathers(MSM_ACC_PARAMS) { accumulate_body<true, true, 1>(MSM_ACC_FWD); }
-__global__ void __launch_bounds__(64) accumulate_whatif_math(MSM_ACC_PARAMS) { accumulate_body<true, true, 2>(MSM_ACC_FWD); }
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) accumulate_whatif_math_w3(MSM_ACC_PARAMS) {
-  accumulate_body<false, false, 2>(MSM_ACC_FWD);
-}
+#include "experiments/k_accumulate_variants.inc"
 #endif
-// Three waves per SIMD: the compiler is held to 168 VGPRs (8 of them spilled outside the loop), no prefetch.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) accumulate_kernel_w3(MSM_ACC_PARAMS) {
-  accumulate_body<false, false>(MSM_ACC_FWD);
-}
-
-// The register-lean build of the same kernel: at most 128 VGPRs, so FOUR waves share a SIMD (the multiplier pipe
-// issues one v_mad_u64_u32 every 5.3 cycles with four waves resident against 6.1 with two, and a simple instruction
-// next to it 4.5 against 5.9: tools/microbench/valu_mix.hip).  Same work items, same results bit for bit.  No
-// software prefetch of the next base: with four waves per SIMD the other three cover the gather.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-accumulate_kernel_lean(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                       const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
-                       const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
-                       const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
-                       uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= counters->total_items) return;
-  const uint2 it = order[slot];
-  const uint32_t b = it.x, j = it.y;
-  const uint32_t size = bucket_size[b];
-  const uint32_t cnt = min(size - j * CH, CH);
-  const uint32_t* idx = sorted + (size_t)(b >> lb) * n + bucket_start[b] + j * CH;
-  PtI acc = pti_identity();
-  enum : uint32_t { kEmpty = 0, kOne = 1, kMany = 2 };
-  uint32_t state = kEmpty;
-  uint32_t next_idx = idx[0];
-  AffPacked pre;
-  pre.x = load_u256(&bases[next_idx & 0x7FFFFFFFu].x);
-  pre.y = load_u256(&bases[next_idx & 0x7FFFFFFFu].y);
-#pragma unroll 1
-  for (uint32_t i = 0; i < cnt; ++i) {
-    const uint32_t cur_idx = next_idx;
-    const AffPacked rec = pre;
-    if (i + 1 < cnt) next_idx = idx[i + 1];
-    // the gather of the next base is issued in the middle of the addition, when the registers are there
-    const auto fetch_next = [&]() {
-      if (i + 1 < cnt) {
-        pre.x = load_u256(&bases[next_idx & 0x7FFFFFFFu].x);
-        pre.y = load_u256(&bases[next_idx & 0x7FFFFFFFu].y);
-      }
-    };
-    const auto unpack = [](const AffPacked& r, uint32_t tagged) {
-      AffI c = affi_unpack_finite(r);
-      const bool negate = (tagged >> 31) != 0;
-      const fe29 ny = Fq29::neg_wide(c.y);
-#pragma unroll
-      for (int l = 0; l < 9; ++l) c.y.l[l] = negate ? ny.l[l] : c.y.l[l];
-      return c;
-    };
-    const auto again = [&]() {
-      AffPacked r;
-      r.x = load_u256(&bases[cur_idx & 0x7FFFFFFFu].x);
-      r.y = load_u256(&bases[cur_idx & 0x7FFFFFFFu].y);
-      return unpack(r, cur_idx);
-    };
-    if (affpacked_is_identity(rec)) {
-      fetch_next();
-      continue;
-    }
-    const AffI cur = unpack(rec, cur_idx);
-    MSM_SCHED_FENCE();
-    if (state == kMany) {
-      MSM_ISA_MARK("begin mixed_addition");
-      if (!pti_madd_lean(acc, cur, again, fetch_next)) state = kEmpty;
-      MSM_ISA_MARK("end");
-    } else if (state == kOne) {
-      MSM_ISA_MARK("begin affine_start");
-      state = pti_mmadd_lean(acc, cur, again, fetch_next) ? (uint32_t)kMany : (uint32_t)kEmpty;
-      MSM_ISA_MARK("end");
-    } else {
-      acc = pti_from_affi(cur);
-      state = kOne;
-      fetch_next();
-    }
-  }
-  if (state == kEmpty) acc = pti_identity();
-  if (size <= CH) {
-    store_pti(&buckets[b], acc);
-  } else {
-    const uint32_t w = b >> lb;
-    store_pti(&partials[(size_t)win_base[w] + item_start[b] + j], acc);
-  }
-}
 
 // Buckets that were split into several items (only skewed digit distributions produce them: equal scalars,
 // the narrow top window of small window sizes).  Two passes over multi_list:
@@ -289,19 +217,29 @@ void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, co
 #define MSM_ACC_ARGS bases, (const uint32_t*)b.sorted, (const uint32_t*)b.bucket_start, (const uint32_t*)b.bucket_size, \
                      (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, (const uint2*)b.order,                \
                      (const PlanCounters*)b.counters, p.n, p.lb, p.CH, buckets, partials
-  if (variant == 2) {
+#if defined(MSM_AMD_EXPERIMENTS)
+  if (variant == 4) {
+    // the hand-allocated kernel (5 waves per SIMD) + the redo pass over the items it flagged (none for ordinary inputs)
+    uint32_t* redo_list = b.redo_list;
+    uint32_t* redo_count = &b.counters->pad[1];
+    hipLaunchKernelGGL(accumulate_kernel_asm, grid, block, 0, st, MSM_ACC_ARGS, redo_list, redo_count);
+    hipLaunchKernelGGL(accumulate_redo_kernel, dim3(1024), block, 0, st, MSM_ACC_ARGS, (const uint32_t*)redo_list,
+                       (const uint32_t*)redo_count);
+  } else if (variant == 2) {
     hipLaunchKernelGGL(accumulate_kernel_lean, grid, block, lds_bytes, st, MSM_ACC_ARGS);
   } else if (variant == 3) {
     hipLaunchKernelGGL(accumulate_kernel_w3, grid, block, lds_bytes, st, MSM_ACC_ARGS);
-#if defined(MSM_AMD_EXPERIMENTS)
+  } else if (variant == 5) {
+    hipLaunchKernelGGL(accumulate_kernel_park, grid, block, 0, st, MSM_ACC_ARGS);
   } else if (variant == 10) {
     hipLaunchKernelGGL(accumulate_whatif_gathers, grid, block, lds_bytes, st, MSM_ACC_ARGS);
   } else if (variant == 11) {
     hipLaunchKernelGGL(accumulate_whatif_math, grid, block, lds_bytes, st, MSM_ACC_ARGS);
   } else if (variant == 12) {
     hipLaunchKernelGGL(accumulate_whatif_math_w3, grid, block, lds_bytes, st, MSM_ACC_ARGS);
+  } else
 #endif
-  } else if (variant == 1) {
+  if (variant == 1) {
     hipLaunchKernelGGL(accumulate_kernel<true>, grid, block, lds_bytes, st, MSM_ACC_ARGS);
   } else {
     hipLaunchKernelGGL(accumulate_kernel<false>, grid, block, lds_bytes, st, MSM_ACC_ARGS);

@@ -655,6 +655,7 @@ size_scan_kernel(uint32_t* __restrict__ wg_bins, uint32_t table_len, uint32_t* _
     counters->total_items = total;
     counters->multi_count = 0;
     counters->pad[0] = 0;   // deferred (big) split buckets, see combine_small_kernel
+    counters->pad[1] = 0;   // work items accumulate_kernel_asm hands to accumulate_redo_kernel
   }
   uint32_t wv = (t < W) ? win_items[t] : 0u;
   uint32_t wtotal;

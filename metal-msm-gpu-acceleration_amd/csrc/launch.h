@@ -58,6 +58,7 @@ struct SortBuffers {
   uint32_t* sorted;           // [W][n]
   uint2* order;               // [max_items] (bucket, chunk) by descending size
   uint32_t* multi_list;       // [max_items] buckets with more than one item
+  uint32_t* redo_list;        // [max_items] work items accumulate_kernel_asm leaves to accumulate_redo_kernel
   PlanCounters* counters;
 };
 

@@ -67,7 +67,7 @@ struct InstanceSlot {
 // 1024-thread sort workgroups of the other stream from being placed at all.)
 struct Workspace {
   DeviceBuf digits, coarse_cnt, region_start, tmp_idx, tmp_fine, tmp_idx2, tmp_fine2, mid_cnt, region_start2, bsize, bstart, istart, win_items, size_bins, sorted,
-      order, multi_list, counters, bases29, buckets, item_partials, S, T, partial, conv_scalars, conv_points,
+      order, multi_list, redo_list, counters, bases29, buckets, item_partials, S, T, partial, conv_scalars, conv_points,
       conv_tmp;
   hipEvent_t front_done = nullptr;    // front stream: sorted indices / work items of this workspace are ready
   hipEvent_t acc_done = nullptr;      // main stream: buckets of this workspace are complete (incl. combine)
@@ -797,6 +797,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   if ((rc = ensure(ctx, w.sorted, (size_t)p.W * n * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.order, p.max_items * sizeof(uint2)))) return rc;
   if ((rc = ensure(ctx, w.multi_list, p.max_items * sizeof(uint32_t)))) return rc;
+  if (ctx->acc_variant == 4 && (rc = ensure(ctx, w.redo_list, p.max_items * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, w.counters, sizeof(PlanCounters)))) return rc;
   const bool prepared = point_layout == MSM_AMD_POINT_PREPARED || tb != nullptr;
   AffPacked* const fill = prepared ? nullptr : ctx->convert_into;   // bases cache fill: convert straight into the entry
@@ -822,6 +823,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   sb.sorted = (uint32_t*)w.sorted.p;
   sb.order = (uint2*)w.order.p;
   sb.multi_list = (uint32_t*)w.multi_list.p;
+  sb.redo_list = (uint32_t*)w.redo_list.p;
   sb.counters = (PlanCounters*)w.counters.p;
 
   // Four streams (front, main, two alternating reduce streams), kWorkspaces workspaces (consecutive instances take
@@ -1709,7 +1711,13 @@ int stage_upload(msm_amd_ctx* ctx, void* dst, const void* src, size_t bytes) {
 // ================================================================================================
 extern "C" {
 
-const char* msm_amd_version(void) { return "msm_amd 0.1 (gfx950)"; }
+const char* msm_amd_version(void) {
+#if defined(MSM_AMD_EXPERIMENTS)
+  return "msm_amd 0.4 (gfx950) +experiments";
+#else
+  return "msm_amd 0.4 (gfx950)";
+#endif
+}
 
 const char* msm_amd_strerror(int status) {
   switch (status) {
@@ -1890,7 +1898,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     Workspace& w = ctx->ws[k];
     DeviceBuf* bufs[] = {&w.digits, &w.coarse_cnt, &w.region_start, &w.tmp_idx, &w.tmp_fine, &w.tmp_idx2, &w.tmp_fine2,
                          &w.mid_cnt, &w.region_start2, &w.bsize, &w.bstart, &w.istart, &w.win_items, &w.size_bins,
-                         &w.sorted, &w.order, &w.multi_list, &w.counters, &w.bases29, &w.buckets, &w.item_partials,
+                         &w.sorted, &w.order, &w.multi_list, &w.redo_list, &w.counters, &w.bases29, &w.buckets, &w.item_partials,
                          &w.S, &w.T, &w.partial, &w.conv_scalars, &w.conv_points, &w.conv_tmp};
     for (DeviceBuf* b : bufs) kill_buf(*b);
   }

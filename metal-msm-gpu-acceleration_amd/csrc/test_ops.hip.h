@@ -38,7 +38,8 @@ MSM_HD void run_test_op(int op, const u256* a, const u256* b, u256* out, uint32_
           case 19: ri = Fq29::norm(Fq29::sub<K16E30>(xi, yi)); break;
           case 20: ri = Fq29::norm(Fq29::sub<K16E31>(xi, y3)); break;
           case 21: ri = Fq29::unpack256(Fq29::pack_canonical(xi)); break;   // incl. the 32-byte storage form
-          // build options measured and not shipped: same values as mul / mul2 / sqr
+#if defined(MSM_AMD_EXPERIMENTS)
+          // build options measured and not shipped (HISTORY.md; -DMSM_AMD_EXPERIMENTS builds only): same values as mul / mul2 / sqr
           case 32: ri = Fq29::mul_karatsuba(xi, yi); break;
           case 33: {   // lockstep product-scanning chains: (x*y, y*y) side by side, their sum checked
             fe29 u, v;
@@ -60,6 +61,7 @@ MSM_HD void run_test_op(int op, const u256* a, const u256* b, u256* out, uint32_
             break;
           }
           case 36: ri = Fq29::mul2_karatsuba_second(xi, yi, yi, xi); break;   // 2 x y
+#endif
         }
         r = Fq29::to_ext(ri);
       }
@@ -141,7 +143,11 @@ MSM_HD void run_test_op(int op, const u256* a, const u256* b, u256* out, uint32_
   po[t] = r;
 }
 
-constexpr int kTestOpMax = 36;   // 27..31 exist on the host only (msm_host.hip), 32..36 are field ops again
+#if defined(MSM_AMD_EXPERIMENTS)
+constexpr int kTestOpMax = 36;   // 27..31 exist on the host only (msm_host.hip), 32..36: the experimental multiplication forms
+#else
+constexpr int kTestOpMax = 31;
+#endif
 MSM_HD bool test_op_is_point(int op) { return (op >= 10 && op <= 13) || (op >= 22 && op <= 26); }
 
 }  // namespace msm_amd

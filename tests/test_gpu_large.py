@@ -219,7 +219,7 @@ def test_log24_ark_affine_dlog_identity(cfg, msm_pkg):
 def test_log26_resident_dlog_identity(cfg, msm_pkg):
     """Four times configs[4]'s size: 2^26 points (4 GiB of bases, 2 GiB of scalars, device-resident), the call runs as
     8 pipelined point ranges of 2^23.  Checked by the dlog identity; 2^28 points (the largest power of two below the
-    API's 2^31 - 1 bound whose buffers the tool builds, 349 ms) are exercised by tools/dbg/big.py, profiles/r03_big_sizes.txt."""
+    API's 2^31 - 1 bound whose buffers the tool builds, 349 ms) are exercised by tools/big_msm.py, profiles/r03_big_sizes.txt."""
     n = 1 << 26
     rng = random.Random(2026)
     a0, d = rng.randrange(o.R_ORDER), rng.randrange(o.R_ORDER)

@@ -1,5 +1,5 @@
 """One MSM of 2^LOG points (default 26), device-resident, checked by the dlog identity (no MSM code on the checking side):
-python tools/dbg/big.py [LOG]"""
+python tools/big_msm.py [LOG]"""
 import importlib, os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import bn254_ref as o

@@ -137,8 +137,8 @@ def main(src, dst):
     out = {"source": "compiler assembly of k_accumulate.hip (hipcc --cuda-device-only -S, flags of the shipped object)",
            "multiplier_instructions": list(MULT), "kernels": {}}
     for name, body in functions(lines):
-        if "accumulate_kernel" not in name:
-            continue
+        if "accumulate_kernel" not in name or "accumulate_kernel_park" in name or "accumulate_kernel_asm" in name:
+            continue   # (the experimental builds with other code shapes are not tallied)
         lean = "accumulate_kernel_lean" in name
         variant = "lean_4_waves" if lean else ("low_occupancy_2_waves" if "ILb1E" in name else "3_waves")
         pc = tally(body)
