@@ -69,6 +69,23 @@ __global__ void __launch_bounds__(64) k_op(const u256* in, uint64_t* out, int it
     }
     t1 = __builtin_amdgcn_s_memtime();
     sinkv = x.l[0] ^ x.l[8];
+  } else if (V == 9) {   // the LDS-parked column-form addition of accumulate_kernel_park (experiments/ec29_variants.inc)
+    __shared__ uint32_t parkmem[27 * 64];
+    struct Pk {
+      uint32_t* base;
+      __device__ fe29 load(int c) const { fe29 r; for (int l = 0; l < 9; ++l) r.l[l] = base[(9 * c + l) * 64]; return r; }
+      __device__ void store(int c, const fe29& v) const { for (int l = 0; l < 9; ++l) base[(9 * c + l) * 64] = v.l[l]; }
+    } pk{parkmem + threadIdx.x};
+    Affine qa; qa.x = xe; qa.y = ye;
+    const AffI q = affi_from_ext(qa);
+    fe29 X = Fq29::from_ext(ye);
+    pk.store(0, q.y); pk.store(1, Fq29::one()); pk.store(2, Fq29::one());
+    const auto again = [&]() { return q; };
+    t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int i = 0; i < iters; ++i) pti_madd_park(X, pk, q, again, [] {});
+    t1 = __builtin_amdgcn_s_memtime();
+    sinkv = X.l[0] ^ pk.load(0).l[3];
   } else if (V == 2 || V == 3) {
     Affine qa; qa.x = xe; qa.y = ye;           // not a curve point: timing only (no exceptional path is taken)
     const AffI q = affi_from_ext(qa);
@@ -301,6 +318,7 @@ int main() {
   run<1>("fips", din, dout, cus, 6000, 1, 6);
   run<2>("madd", din, dout, cus, 800, 1, 3);
   run<3>("madd_lean", din, dout, cus, 800, 1, 4);
+  run<9>("madd_park", din, dout, cus, 800, 1, 4);
   run<4>("straight", din, dout, cus, 40, 2048, 8);     // per multiply-add
   run<5>("tight", din, dout, cus, 5120, 16, 8);        // per multiply-add
   run_asmb<0>("asm mul", dout, cus);
