@@ -303,8 +303,8 @@ def main(argv=None):
     # isa_counts.json).
     # ONE peak (round 4), measured in shader cycles by the waves themselves (s_memtime; tools/microbench/mul_occ.hip,
     # profiles/r04_mul_occupancy_microbench.txt, row "straight"): back-to-back independent v_mad_u64_u32 issue every
-    # 4.0 cycles per SIMD at the shipped kernel's occupancy of 2 waves per SIMD (8.0 per wave; 2.0-3.0 per SIMD only
-    # with 8 waves resident, which the mixed addition's ~170 live registers rule out).  x 1024 SIMDs x 64 lanes at the
+    # 4.0 cycles per SIMD at the shipped kernel's occupancy of 2 waves per SIMD (8.0 per wave) and NOT faster with more
+    # waves (whole-launch timing, LAUNCH column of the same file: 1.9 ns from 2 to 8 waves).  x 1024 SIMDs x 64 lanes at the
     # nominal 2.4 GHz = 39.3 T lane-instructions/s.  A simple instruction (v_add_u32) issues every 2.9 cycles per SIMD
     # at the same occupancy (profiles/r04_valu_peak_microbench.txt); `valu_issue_utilisation` prices every VALU
     # instruction of the launch (SQ_INSTS_VALU of profiles/pmc_traffic.json) at those two figures against the SIMD

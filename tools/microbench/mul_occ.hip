@@ -1,5 +1,6 @@
-// Does the 29-bit-limb field arithmetic get faster with more waves per SIMD?  Measured in shader cycles by the
-// waves themselves (s_memtime) at occupancies the launch really has: one 64-lane workgroup per wave, the waves per SIMD
+// Does the 29-bit-limb field arithmetic get faster with more waves per SIMD?  No: read the LAUNCH column (HIP-event time of
+// the whole launch per operation per SIMD).  The per-wave columns (a wave's own s_memtime cycles / k) overstate the
+// throughput beyond two waves, because the waves of a SIMD are not resident for the same span.  Occupancies are real: one 64-lane workgroup per wave, the waves per SIMD
 // capped through the REGISTER allocation (the kernel touches VGPR 512 / k - 1, so exactly k waves fit a SIMD's 512; an
 // LDS cap limits the waves per CU but lets the dispatcher put eight on one SIMD and none on the next -- the first
 // version of this benchmark did that, and its odd "4 waves are slower than 3" rows were placement).  Every wave also
@@ -21,7 +22,10 @@
 #include <vector>
 #include "../../metal-msm-gpu-acceleration_amd/csrc/bn254_ec29.hip.h"
 using namespace msm_amd;
-#include "asm_bench.inc"   // tools/gen_accumulate_asm.py with MSM_ASM_BENCH=1: the kernel statement + timing-only statements
+#include "asm_bench.inc"
+#if __has_include("cmul_bench.inc")
+#include "cmul_bench.inc"   // experiment: the COMPILER's multiplication loop body transplanted into a statement
+#endif   // tools/gen_accumulate_asm.py with MSM_ASM_BENCH=1: the kernel statement + timing-only statements
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 #define MADV(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(m[i]) : "v"(a), "v"(b) : "vcc");
@@ -115,7 +119,10 @@ __global__ void __launch_bounds__(64) k_op(const u256* in, uint64_t* out, int it
   }
   if (sinkv == 0x12345u) out[0] = sinkv;
   if (threadIdx.x == 0) {
-    out[1 + 2 * blockIdx.x] = ((t1 - t0) & 0xFFFFFFFFFFull) | ((__builtin_amdgcn_s_memrealtime() - q0) << 40);   // cycles | 100 MHz ticks
+    const uint64_t q1 = __builtin_amdgcn_s_memrealtime();
+    out[1 + 2 * blockIdx.x] = ((t1 - t0) & 0xFFFFFFFFFFull) | ((q1 - q0) << 40);   // cycles | 100 MHz ticks
+    out[40000 + 2 * blockIdx.x] = q0;
+    out[40001 + 2 * blockIdx.x] = q1;
     // HW_ID: wave_id [3:0], simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID register 20, bits [3:0]
     const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
     out[2 + 2 * blockIdx.x] = ((uint64_t)xcc << 32) | hw;
@@ -161,7 +168,7 @@ __global__ void __launch_bounds__(64) k_asmb(uint32_t iters, uint64_t* out) {
   }
   const uint32_t lds128 = lds0 + threadIdx.x * 16u, lds32 = lds0 + 6u * 1024u + threadIdx.x * 4u, cnt = iters;
   const uint64_t t0 = __builtin_amdgcn_s_memtime(), q0 = __builtin_amdgcn_s_memrealtime();
-#define BENCH_OPERANDS : : [cnt] "v"(cnt), [lds128] "v"(lds128), [lds32] "v"(lds32), \
+#define BENCH_OPERANDS : : [cnt] "v"(cnt), [scnt] "s"(iters), [seed] "v"(threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u), [lds128] "v"(lds128), [lds32] "v"(lds32), \
                  [p0] "s"(Fq29::p(0)), [p1] "s"(Fq29::p(1)), [p2] "s"(Fq29::p(2)), [p3] "s"(Fq29::p(3)), \
                  [p4] "s"(Fq29::p(4)), [p5] "s"(Fq29::p(5)), [p6] "s"(Fq29::p(6)), [p7] "s"(Fq29::p(7)), \
                  [p8] "s"(Fq29::p(8)), [inv] "s"(Fq29::INV) : MSM_ACC_ASM_CLOBBERS
@@ -173,6 +180,11 @@ __global__ void __launch_bounds__(64) k_asmb(uint32_t iters, uint64_t* out) {
   if (B == 5) asm volatile(MSM_ACC_ASM_BENCH_MUL_NONOP BENCH_OPERANDS);
   if (B == 7) asm volatile(MSM_ACC_ASM_BENCH_MUL_IL BENCH_OPERANDS);
   if (B == 8) asm volatile(MSM_ACC_ASM_BENCH_MUL_PV BENCH_OPERANDS);
+#if defined(MSM_ACC_ASM_BENCH_CMUL)
+  if (B == 9) asm volatile(MSM_ACC_ASM_BENCH_CMUL BENCH_OPERANDS);
+  if (B == 10) asm volatile(MSM_ACC_ASM_BENCH_CMUL_S BENCH_OPERANDS);
+  if (B == 11) asm volatile(MSM_ACC_ASM_BENCH_CMUL_D BENCH_OPERANDS);
+#endif
   const uint64_t t1 = __builtin_amdgcn_s_memtime(), q1 = __builtin_amdgcn_s_memrealtime();
   if (threadIdx.x == 0) {
     out[40000 + 2 * blockIdx.x] = q0;   // absolute 100 MHz ticks: were the waves of a SIMD resident TOGETHER?
@@ -186,7 +198,13 @@ __global__ void __launch_bounds__(64) k_asmb(uint32_t iters, uint64_t* out) {
 template <int B, int K>
 void run_asmb_one(uint64_t* dout, int cus, uint32_t iters) {
   const int blocks = cus * 4 * K;
-  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k_asmb<B, K>), dim3(blocks), dim3(64), 0, 0, iters, dout);
+  hipLaunchKernelGGL((k_asmb<B, K>), dim3(blocks), dim3(64), 0, 0, iters, dout);
+  CHECK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL((k_asmb<B, K>), dim3(blocks), dim3(64), 0, 0, iters, dout);
+  CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+  float launch_ms = 0; CHECK(hipEventElapsedTime(&launch_ms, e0, e1));
   std::vector<uint64_t> h2(40000 + 2 * blocks + 2);
   CHECK(hipMemcpy(h2.data(), dout, h2.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
   std::vector<uint64_t> t; std::vector<double> ghz; std::map<uint64_t, int> per_simd;
@@ -203,7 +221,8 @@ void run_asmb_one(uint64_t* dout, int cus, uint32_t iters) {
   int lo = 1 << 30, hi = 0;
   for (auto& kv : per_simd) { lo = std::min(lo, kv.second); hi = std::max(hi, kv.second); }
   const double g = ghz[ghz.size() / 2], slow = (double)t.back() / ((double)iters * K);
-  printf("  %dw %7.1f..%7.1f cyc @%.2f GHz = %6.1f ns [%d..%d w/SIMD]", K, (double)t[0] / ((double)iters * K), slow, g, slow / g, lo, hi);
+  printf("  %dw %7.1f..%7.1f cyc @%.2f GHz = %6.1f ns [%d..%d w/SIMD] LAUNCH %6.1f ns", K, (double)t[0] / ((double)iters * K), slow, g, slow / g, lo, hi,
+         launch_ms * 1e6 / ((double)iters * K));
   if (K == 5 && B == 0) {   // residency of the waves of one SIMD (us from the first start)
     auto& v = spans.begin()->second;
     std::sort(v.begin(), v.end());
@@ -264,13 +283,20 @@ template <int V, int K>
 void run_one(const u256* din, uint64_t* dout, int cus, int iters, double ops_per_iter) {
   const int blocks = cus * 4 * K;
   hipLaunchKernelGGL((k_op<V, K>), dim3(blocks), dim3(64), 0, 0, din, dout, iters);
+  CHECK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  CHECK(hipEventRecord(e0));
   hipLaunchKernelGGL((k_op<V, K>), dim3(blocks), dim3(64), 0, 0, din, dout, iters);
-  std::vector<uint64_t> h(1 + 2 * blocks);
+  CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+  float launch_ms = 0; CHECK(hipEventElapsedTime(&launch_ms, e0, e1));
+  std::vector<uint64_t> h(40000 + 2 * blocks + 2);
   CHECK(hipMemcpy(h.data(), dout, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
   std::vector<uint64_t> t;
   std::map<uint64_t, int> per_simd;
+  std::map<uint64_t, std::vector<std::pair<uint64_t, uint64_t>>> spans;
   std::vector<double> ghz;
   for (int b = 0; b < blocks; ++b) {
+    spans[((h[2 + 2 * b] >> 32) << 16) | ((h[2 + 2 * b] & 0xFFFF) >> 4)].push_back({h[40000 + 2 * b], h[40001 + 2 * b]});
     t.push_back(h[1 + 2 * b] & 0xFFFFFFFFFFull);
     ghz.push_back((double)(h[1 + 2 * b] & 0xFFFFFFFFFFull) / ((double)(h[1 + 2 * b] >> 40) * 10.0));
     const uint64_t id = h[2 + 2 * b];
@@ -283,8 +309,14 @@ void run_one(const u256* din, uint64_t* dout, int cus, int iters, double ops_per
   std::sort(ghz.begin(), ghz.end());
   const double g = ghz[ghz.size() / 2], slow = (double)t.back() / (iters * ops_per_iter * K);
   // cycles: fastest .. slowest wave; shader clock (median wave, from s_memrealtime); ns per operation per SIMD at that clock
-  printf("  %dw %7.1f..%7.1f cyc @%.2f GHz = %6.1f ns [%d..%d w/SIMD]", K, (double)t[0] / (iters * ops_per_iter * K), slow, g,
-         slow / g, lo, hi);
+  printf("  %dw %7.1f..%7.1f cyc @%.2f GHz = %6.1f ns [%d..%d w/SIMD] LAUNCH %6.1f ns", K, (double)t[0] / (iters * ops_per_iter * K), slow, g,
+         slow / g, lo, hi, launch_ms * 1e6 / (iters * ops_per_iter * K));
+  if (false) {
+    auto& v = spans.begin()->second;
+    std::sort(v.begin(), v.end());
+    printf("\n      one SIMD's waves, start..end in us:");
+    for (auto& se : v) printf(" %.0f..%.0f", (se.first - v[0].first) / 100.0, (se.second - v[0].first) / 100.0);
+  }
 }
 template <int V>
 void run(const char* name, const u256* din, uint64_t* dout, int cus, int iters, double ops_per_iter, int max_k) {
@@ -323,6 +355,11 @@ int main() {
   run<5>("tight", din, dout, cus, 5120, 16, 8);        // per multiply-add
   run_asmb<0>("asm mul", dout, cus);
   run_asmb<6>("asm mul-l", dout, cus);     // the same statement in a kernel without an LDS allocation
+#if defined(MSM_ACC_ASM_BENCH_CMUL)
+  run_asmb<9>("cmul asm", dout, cus);      // the compiler's loop body as a statement
+  run_asmb<10>("cmul asm s", dout, cus);   // ... with a scalar loop counter (no VALU-written vcc branch)
+  run_asmb<11>("cmul asm d", dout, cus);   // ... and every register initialised with lane-dependent 29-bit values
+#endif
   run_asmb<7>("asm mul i", dout, cus);     // reduction of row i interleaved with the products of row i + 1
   run_asmb<8>("asm mul p", dout, cus);     // the limbs of p in VGPRs instead of SGPRs
   run_asmb<3>("asm mul s", dout, cus);     // carry-out to an SGPR pair instead of vcc
