@@ -158,6 +158,78 @@ MSM_HD PtI pti_double(const PtI& p) {   // p not the identity
 // `vanished` is set when the sum is the identity (q == -p); the caller tracks that state instead of testing limbs.
 // MSM_FQ29_LOCKSTEP: the independent products of the formula run side by side as lockstep product-scanning chains
 // (Fq29::fips_multi): (U2, S2), (PP, RR), (PPP, Q, ZZ3), (Y3, ZZZ3).
+// The mixed addition in two steps, for a caller that re-uses q's registers in between (accumulate_kernel gathers the
+// next base into them): the head consumes q, the tail needs it again only in the exceptional case q == p and asks
+// `reload_q` for it.  pti_madd below is head + tail.
+// Pins (pin_limbs, bn254_fq29.hip.h) are set ONCE per basic block and the pinned value replaces the old one -- p.zz and
+// p.zzz in the head (hence the non-const p), everything the long block of the tail reads at its top -- and the
+// multiplications inside run without pins of their own.
+MSM_HD void pti_madd_head(PtI& p, const fe29& qx, const fe29& qy, fe29& U2, fe29& S2) {
+  p.zz = pin_limbs(p.zz);
+  p.zzz = pin_limbs(p.zzz);
+  U2 = Fq29::mul_np(pin_limbs(qx), p.zz);
+  S2 = Fq29::mul_np(pin_limbs(qy), p.zzz);
+}
+template <class ReloadQ>
+MSM_HD PtI pti_madd_tail(const PtI& p, const fe29& U2, const fe29& S2, ReloadQ&& reload_q, bool& vanished) {
+  const fe29 P0 = Fq29::norm(Fq29::sub<K16E30>(U2, p.x));   // < 17.1 p
+  const fe29 R0 = Fq29::norm(Fq29::sub<K8E30>(S2, p.y));    // <  9.1 p
+  if (Fq29::maybe_zero(P0, 18)) {
+    MSM_ISA_MARK("rare mixed_addition");
+    if (Fq29::is_zero_exact(P0)) {   // same x: either q == p (double) or q == -p (identity)
+      if (Fq29::is_zero_exact(R0)) return pti_double(pti_from_affi(reload_q()));
+      vanished = true;
+      return pti_identity();
+    }
+  }
+  MSM_ISA_MARK("resume mixed_addition");
+  const fe29 P = pin_limbs(P0), R = pin_limbs(R0), X1 = pin_limbs(p.x), Y1 = pin_limbs(p.y), ZZ1 = pin_limbs(p.zz),
+             ZZZ1 = pin_limbs(p.zzz);   // one block from here on: no pins inside
+  PtI r;
+  const fe29 PP = Fq29::sqr_np(P);
+  const fe29 PPP = Fq29::mul_np(P, PP);
+  const fe29 Q = Fq29::mul_np(X1, PP);
+  const fe29 RR = Fq29::sqr_np(R);
+  r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.5 p
+  // T and -PPP stay un-normalised (limbs < 2^31 / 2^30.5): their partners R and Y1 in the double product are
+  // normalised, and tools/fq29_bounds.py checks that no column of R*T + Y1*(-PPP) can reach 2^64
+  const fe29 T = Fq29::sub<K16E30>(Q, r.x);                                               // < 17.2 p
+  r.y = Fq29::mul2_np(R, T, Y1, Fq29::neg_wide(PPP));   // R*T - Y1*PPP in one reduction       // < 1.2 p
+  r.zz = Fq29::mul_np(ZZ1, PP);
+  r.zzz = Fq29::mul_np(ZZZ1, PPP);
+  return r;
+}
+// The affine + affine start likewise: the head consumes q.
+MSM_HD void pti_mmadd_head(const fe29& px, const fe29& py, const fe29& qx, const fe29& qy, fe29& P, fe29& R) {
+  P = Fq29::norm(Fq29::sub<K16E30>(qx, px));   // < 17.1 p
+  R = Fq29::norm(Fq29::sub<K8E30>(qy, py));    // < 12.1 p (q.y may be an un-normalised negation, py not)
+}
+template <class ReloadQ>
+MSM_HD PtI pti_mmadd_tail(const fe29& px, const fe29& py, const fe29& P, const fe29& R, ReloadQ&& reload_q,
+                          bool& vanished) {
+  if (Fq29::maybe_zero(P, 18)) {
+    MSM_ISA_MARK("rare affine_start");
+    if (Fq29::is_zero_exact(P)) {   // same x: either q == p (double) or q == -p (identity)
+      if (Fq29::is_zero_exact(R)) return pti_double(pti_from_affi(reload_q()));
+      vanished = true;
+      return pti_identity();
+    }
+  }
+  MSM_ISA_MARK("resume affine_start");
+  const fe29 Pp = pin_limbs(P), Rp = pin_limbs(R), X1 = pin_limbs(px), Y1 = pin_limbs(py);   // one block from here on
+  const fe29 PP = Fq29::sqr_np(Pp);
+  const fe29 PPP = Fq29::mul_np(Pp, PP);
+  const fe29 Q = Fq29::mul_np(X1, PP);
+  const fe29 RR = Fq29::sqr_np(Rp);
+  PtI r;
+  r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.9 p
+  const fe29 T = Fq29::norm(Fq29::sub<K16E30>(Q, r.x));                                   // < 17.2 p
+  r.y = Fq29::mul2_np(Rp, T, Y1, Fq29::neg_wide(PPP));   // R*T - Y1*PPP in one reduction      // < 1.2 p
+  r.zz = PP;                                                                              // < 2.8 p
+  r.zzz = PPP;
+  return r;
+}
+
 MSM_HD PtI pti_madd(const PtI& p, const AffI& q, bool& vanished) {
 #if defined(MSM_AMD_EXPERIMENTS) && defined(MSM_FQ29_LOCKSTEP)
   fe29 U2, S2;
@@ -166,9 +238,12 @@ MSM_HD PtI pti_madd(const PtI& p, const AffI& q, bool& vanished) {
   const fe29 U2 = Fq29::mul_karatsuba(q.x, p.zz);
   const fe29 S2 = Fq29::mul_karatsuba(q.y, p.zzz);
 #else
-  const fe29 U2 = Fq29::mul(q.x, p.zz);
-  const fe29 S2 = Fq29::mul(q.y, p.zzz);
+  fe29 U2, S2;
+  PtI pp = p;
+  pti_madd_head(pp, q.x, q.y, U2, S2);
+  return pti_madd_tail(pp, U2, S2, [&]() { return q; }, vanished);
 #endif
+#if defined(MSM_AMD_EXPERIMENTS) && (defined(MSM_FQ29_LOCKSTEP) || defined(MSM_FQ29_KARATSUBA))
   const fe29 P = Fq29::norm(Fq29::sub<K16E30>(U2, p.x));   // < 17.1 p
   const fe29 R = Fq29::norm(Fq29::sub<K8E30>(S2, p.y));    // <  9.1 p
   if (Fq29::maybe_zero(P, 18)) {
@@ -198,20 +273,9 @@ MSM_HD PtI pti_madd(const PtI& p, const AffI& q, bool& vanished) {
   r.y = Fq29::mul2_karatsuba_second(R, T, p.y, Fq29::neg_wide(PPP));
   r.zz = Fq29::mul_karatsuba(p.zz, PP);
   r.zzz = Fq29::mul_karatsuba(p.zzz, PPP);
-#else
-  const fe29 PP = Fq29::sqr(P);
-  const fe29 PPP = Fq29::mul(P, PP);
-  const fe29 Q = Fq29::mul(p.x, PP);
-  const fe29 RR = Fq29::sqr(R);
-  r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.5 p
-  // T and -PPP stay un-normalised (limbs < 2^31 / 2^30.5): their partners R and Y1 in the double product are
-  // normalised, and tools/fq29_bounds.py checks that no column of R*T + Y1*(-PPP) can reach 2^64
-  const fe29 T = Fq29::sub<K16E30>(Q, r.x);                                               // < 17.2 p
-  r.y = Fq29::mul2(R, T, p.y, Fq29::neg_wide(PPP));   // R*T - Y1*PPP in one reduction         // < 1.2 p
-  r.zz = Fq29::mul(p.zz, PP);
-  r.zzz = Fq29::mul(p.zzz, PPP);
 #endif
   return r;
+#endif
 }
 
 // p + q, BOTH affine, neither the identity (the second point of every work item: the accumulator was just set
@@ -219,28 +283,9 @@ MSM_HD PtI pti_madd(const PtI& p, const AffI& q, bool& vanished) {
 // 4M + 2S.  (px, py) = p with px < 9.5 p, py < 6 p as in pti_madd; q.y may be a lazily negated value < 4 p.
 // The result obeys the same bounds as pti_madd's.
 MSM_HD PtI pti_mmadd(const fe29& px, const fe29& py, const AffI& q, bool& vanished) {
-  const fe29 P = Fq29::norm(Fq29::sub<K16E30>(q.x, px));   // < 17.1 p
-  const fe29 R = Fq29::norm(Fq29::sub<K8E30>(q.y, py));    // < 12.1 p (q.y may be an un-normalised negation, py not)
-  if (Fq29::maybe_zero(P, 18)) {
-    MSM_ISA_MARK("rare affine_start");
-    if (Fq29::is_zero_exact(P)) {   // same x: either q == p (double) or q == -p (identity)
-      if (Fq29::is_zero_exact(R)) return pti_double(pti_from_affi(q));
-      vanished = true;
-      return pti_identity();
-    }
-  }
-  MSM_ISA_MARK("resume affine_start");
-  const fe29 PP = Fq29::sqr(P);
-  const fe29 PPP = Fq29::mul(P, PP);
-  const fe29 Q = Fq29::mul(px, PP);
-  const fe29 RR = Fq29::sqr(R);
-  PtI r;
-  r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.9 p
-  const fe29 T = Fq29::norm(Fq29::sub<K16E30>(Q, r.x));                                   // < 17.2 p
-  r.y = Fq29::mul2(R, T, py, Fq29::neg_wide(PPP));   // R*T - Y1*PPP in one reduction          // < 1.2 p
-  r.zz = PP;                                                                              // < 2.8 p
-  r.zzz = PPP;
-  return r;
+  fe29 P, R;
+  pti_mmadd_head(px, py, q.x, q.y, P, R);
+  return pti_mmadd_tail(px, py, P, R, [&]() { return q; }, vanished);
 }
 
 

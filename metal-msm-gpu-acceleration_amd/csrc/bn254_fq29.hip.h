@@ -176,8 +176,12 @@ struct Fq29 {
 #endif
 
   // a*b*rho^-1 mod p (lazily reduced).  81 + 81 limb products, no carry instructions.
+  // PIN = false (mul_np / mul2_np / sqr_np below): the caller has pinned the operands itself, ONCE per basic block
+  // (pin_limbs on a value that is used again later costs a v_mov per limb: the empty asm's output is a new value, the
+  // old one must survive beside it.  Pinning inside every multiplication cost the mixed addition 81 v_mov.)
+  template <bool PIN = true>
   MSM_HD static fe29 mul(const fe29& a_in, const fe29& b_in) {
-    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in);
+    const fe29 a = PIN ? pin_limbs(a_in) : a_in, b = PIN ? pin_limbs(b_in) : b_in;
 #if defined(MSM_AMD_EXPERIMENTS) && defined(MSM_FQ29_FIPS)
     {
       const fe29* const xs[1] = {&a};
@@ -200,8 +204,10 @@ struct Fq29 {
   // (a*b + c*d)*rho^-1 with ONE Montgomery reduction: 81 + 81 + 81 limb products instead of 2 x (81 + 81).
   // All four operands must be normalised (limbs <= 2^29 + 8) so that a column of 18 + 9 products stays
   // below 2^64.  Used for Y3 = R*T - Y1*PPP with d = -PPP.
+  template <bool PIN = true>
   MSM_HD static fe29 mul2(const fe29& a_in, const fe29& b_in, const fe29& c_in, const fe29& d_in) {
-    const fe29 a = pin_limbs(a_in), b = pin_limbs(b_in), c = pin_limbs(c_in), d = pin_limbs(d_in);
+    const fe29 a = PIN ? pin_limbs(a_in) : a_in, b = PIN ? pin_limbs(b_in) : b_in, c = PIN ? pin_limbs(c_in) : c_in,
+               d = PIN ? pin_limbs(d_in) : d_in;
 #if defined(MSM_AMD_EXPERIMENTS) && defined(MSM_FQ29_FIPS)
     {
       const fe29* const xs[2] = {&a, &c};
@@ -225,8 +231,9 @@ struct Fq29 {
   }
 
   // a*a*rho^-1: 45 + 81 limb products (cross products use the doubled operand).
+  template <bool PIN = true>
   MSM_HD static fe29 sqr(const fe29& a_in) {
-    const fe29 a = pin_limbs(a_in);
+    const fe29 a = PIN ? pin_limbs(a_in) : a_in;
 #if defined(MSM_AMD_EXPERIMENTS) && defined(MSM_FQ29_FIPS)
     {
       fe29 d2;
@@ -250,6 +257,9 @@ struct Fq29 {
     }
     return reduce_columns(A);
   }
+  MSM_HD static fe29 mul_np(const fe29& a, const fe29& b) { return mul<false>(a, b); }
+  MSM_HD static fe29 sqr_np(const fe29& a) { return sqr<false>(a); }
+  MSM_HD static fe29 mul2_np(const fe29& a, const fe29& b, const fe29& c, const fe29& d) { return mul2<false>(a, b, c, d); }
 
   // 256-bit little-endian integer -> 9 x 29-bit limbs (pure bit slicing, value unchanged).
   MSM_HD static fe29 unpack256(const u256& x) {

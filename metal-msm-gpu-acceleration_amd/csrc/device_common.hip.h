@@ -78,6 +78,32 @@ __device__ __forceinline__ void store_affine(Affine* p, const Affine& a) {
   store_u256(&p->y, a.y);
 }
 
+#if defined(MSM_AMD_EXPERIMENTS)
+// The wide record of a base (experiments/ec29_variants.inc, accumulate variant 8): stored as eight 16-byte pieces; read as x (9 words at the start of the
+// 128-byte line) and ONE of y / -y (9 words at byte 36 or 72, picked by the sign bit of the sorted entry).
+__device__ __forceinline__ void store_wide(AffWide* p, const AffWide& a) {
+  const uint32_t* w = a.x;   // x, y, ny, pad are contiguous (static_assert on the size)
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+typedef uint32_t u32x4_dword_aligned __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void load_wide(const AffWide* __restrict__ bases, uint32_t entry, AffI& q) {
+  const uint32_t* r = reinterpret_cast<const uint32_t*>(bases + (entry & 0x7FFFFFFFu));
+  const uint4 a = *reinterpret_cast<const uint4*>(r), b = *reinterpret_cast<const uint4*>(r + 4);
+  q.x.l[0] = a.x; q.x.l[1] = a.y; q.x.l[2] = a.z; q.x.l[3] = a.w;
+  q.x.l[4] = b.x; q.x.l[5] = b.y; q.x.l[6] = b.z; q.x.l[7] = b.w;
+  q.x.l[8] = r[8];
+  const uint32_t* ry = r + 9 + 9 * (entry >> 31);   // negative digit: the stored -y
+  const u32x4_dword_aligned c = *reinterpret_cast<const u32x4_dword_aligned*>(ry);
+  const u32x4_dword_aligned d = *reinterpret_cast<const u32x4_dword_aligned*>(ry + 4);
+  q.y.l[0] = c.x; q.y.l[1] = c.y; q.y.l[2] = c.z; q.y.l[3] = c.w;
+  q.y.l[4] = d.x; q.y.l[5] = d.y; q.y.l[6] = d.z; q.y.l[7] = d.w;
+  q.y.l[8] = ry[8];
+}
+__device__ __forceinline__ bool wide_is_identity(const AffI& q) { return q.x.l[8] == 0xFFFFFFFFu; }
+#endif
+
 __device__ __forceinline__ Jacobian load_jac(const Jacobian* p) {
   Jacobian r;
   r.x = load_u256(&p->x);

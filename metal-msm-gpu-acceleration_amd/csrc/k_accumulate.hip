@@ -6,30 +6,38 @@
 namespace msm_amd {
 
 // One lane per work item.  A work item is (bucket b, chunk j): points [j*CH, min(size, (j+1)*CH)) of the
-// bucket's slice of `sorted`.  The lane gathers each 64-byte packed affine base and performs a mixed XYZZ+affine addition on 29-bit limbs (pti_madd, madd-2008-s, 8M+2S).  Items arrive sorted by
-// descending length (`order`), so the 64 lanes of a wave run the same number of iterations and the
-// longest items start first.  Replaces kernel bucket_wise_accumulation (msm.h.metal:75-315), which
-// splits pairs evenly over threads and merges bucket boundaries through threadgroup memory.
+// bucket's slice of `sorted`.  The lane gathers each 64-byte packed affine base and performs a mixed XYZZ+affine addition
+// on 29-bit limbs (madd-2008-s, 8M+2S).  Items arrive sorted by descending length (`order`), so the 64 lanes of a wave
+// run the same number of iterations and the longest items start first.  Replaces kernel bucket_wise_accumulation
+// (msm.h.metal:75-315), which splits pairs evenly over threads and merges bucket boundaries through threadgroup memory.
 //
 // A bucket made of one item is written straight to buckets[b]; a split bucket writes its partial sums
 // to partials[window_base + item_start[b] + j] and combine_kernel adds them up.
-// LOW_OCC = true pins a high VGPR so that the kernel runs at 2 instead of 3 waves per SIMD (about 3 % slower
-// alone): with several streams in flight this leaves register file and wave slots for the sort / reduce
-// kernels of the neighbouring instance, which otherwise cannot be placed until the whole accumulate grid has
-// drained (measured: a 1024-thread plan_kernel workgroup waited 1.4 ms behind 3-wave accumulate waves).
-// PREFETCH: gather the packed record of point i + 1 while point i is added (16 more live registers).
-// PIN: touch v175 so that the kernel allocates 176 VGPRs and runs at two waves per SIMD whatever it needs itself.
-template <bool PREFETCH, bool PIN, int WHATIF = 0>
+//
+// What the accumulator holds is tracked in a lane register instead of being read off its limbs every trip:
+//   kEmpty  the identity (nothing added yet, or a sum that cancelled)
+//   kOne    exactly one base, still affine (ZZ = ZZZ = 1): the next addition is affine + affine, 4M + 2S
+//   kMany   a general XYZZ point: mixed additions, 8M + 2S
+// The loop is shaped for the register allocator (round 4, late; profiles/r04_accumulate_loop_shape.txt):
+//   * phase A handles the first points of the item (kEmpty / kOne), phase B is a loop that holds nothing but the mixed
+//     addition, so the accumulator stays in ONE set of registers (the three-way merge of a single loop cost 18 v_mov
+//     per trip);
+//   * software pipeline: the packed record of point i + 1 is gathered while point i is added (a whole mixed addition,
+//     ~7 us at two waves per SIMD, hides the gather); the record is unpacked BEFORE the next gather is issued into the
+//     SAME registers (loading first and unpacking later cost 2 x 8 v_mov_b64 per trip);
+//   * the addition runs as head + tail (bn254_ec29.hip.h) with operands pinned once per basic block: the base dies in
+//     the head, and the exceptional case q == p, which needs it again, gathers it again.
+// PIN: touch v175 so that the kernel allocates at least 176 VGPRs and runs at TWO waves per SIMD whatever it needs itself
+// (it needs 180): with several streams in flight this leaves register file and wave slots for the sort / reduce kernels
+// of the neighbouring instances, which otherwise cannot be placed until the whole accumulate grid has drained (measured
+// in round 1: a 1024-thread plan_kernel workgroup waited 1.4 ms behind 3-wave accumulate waves).
+template <bool PIN>
 __device__ __forceinline__ void
 accumulate_item(const uint32_t slot, const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
-                const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
-                const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
-                uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
-  constexpr bool LOW_OCC = PREFETCH;
-  // WHATIF (timing experiments, -DMSM_AMD_EXPERIMENTS builds only): 1 = gathers without arithmetic, 2 = arithmetic
-  // on a 1 MB slice of the bases (every gather hits the L2)
-  constexpr uint32_t IDX_MASK = WHATIF == 2 ? 0x3FFFu : 0x7FFFFFFFu;
+                   const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
+                   const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
+                   const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
+                   uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
   if (PIN) asm volatile("v_mov_b32 v175, 0" ::: "v175");
   if (slot >= counters->total_items) return;
   const uint2 it = order[slot];
@@ -40,71 +48,87 @@ accumulate_item(const uint32_t slot, const AffPacked* __restrict__ bases, const 
   const uint32_t cnt = min(size - lo, CH);
   const uint32_t* idx = sorted + (size_t)w * n + bucket_start[b] + lo;
   PtI acc = pti_identity();
-  // What acc holds is tracked in a lane register instead of being read off its limbs every trip:
-  //   kEmpty  the identity (nothing added yet, or a sum that cancelled)
-  //   kOne    exactly one base, still affine (ZZ = ZZZ = 1): the next addition is affine + affine, 4M + 2S
-  //   kMany   a general XYZZ point: mixed additions, 8M + 2S
   enum : uint32_t { kEmpty = 0, kOne = 1, kMany = 2 };
   uint32_t state = kEmpty;
-  // Software pipeline.  LOW_OCC (2 waves/SIMD) has ~20 spare VGPRs: the packed 64-byte record of point i + 1 is
-  // gathered while point i is added, so a whole mixed addition (~5 us) hides the gather.  The 3-wave variant has
-  // no registers to spare: it issues the gather at the top of the iteration and first consumes it after the
-  // Z1^2 squaring inside pti_madd, prefetching only the next index.
   uint32_t cur_idx = idx[0];
   uint32_t next_idx = cnt > 1 ? idx[1] : 0u;
   AffPacked pre;
-  if (LOW_OCC) {
-    pre.x = load_u256(&bases[cur_idx & IDX_MASK].x);
-    pre.y = load_u256(&bases[cur_idx & IDX_MASK].y);
-  }
-#pragma unroll 1
-  for (uint32_t i = 0; i < cnt; ++i) {
+  pre.x = load_u256(&bases[cur_idx & 0x7FFFFFFFu].x);
+  pre.y = load_u256(&bases[cur_idx & 0x7FFFFFFFu].y);
+  uint32_t i = 0;
+  // take(): point i in register form (negated for a negative digit), whether it is the identity; starts the gather of
+  // point i + 1 into the registers it has just emptied and the load of index i + 2
+  // register form of a gathered record: unpacked, y negated for a negative digit (-y without the carry round, limbs
+  // < 2^30.5: y only ever multiplies the normalised ZZZ1 or enters the lifted subtraction of pti_mmadd; bounds:
+  // tools/fq29_bounds.py)
+  auto signed_point = [](const AffPacked& rec, uint32_t entry) {
+    AffI r = affi_unpack_finite(rec);
+    const bool negate = (entry >> 31) != 0;
+    const fe29 ny = Fq29::neg_wide(r.y);
+#pragma unroll
+    for (int l = 0; l < 9; ++l) r.y.l[l] = negate ? ny.l[l] : r.y.l[l];
+    return r;
+  };
+  // the exceptional case q == p (a doubling) needs q after its registers have been given away: gathered again
+  auto regather = [&](uint32_t entry) {
     AffPacked rec;
-    if (LOW_OCC) {
-      rec = pre;
-      if (i + 1 < cnt) {
-        pre.x = load_u256(&bases[next_idx & IDX_MASK].x);
-        pre.y = load_u256(&bases[next_idx & IDX_MASK].y);
-      }
-    } else {
-      rec.x = load_u256(&bases[cur_idx & IDX_MASK].x);
-      rec.y = load_u256(&bases[cur_idx & IDX_MASK].y);
-    }
-    const bool negate = (cur_idx >> 31) != 0;   // negative digit: add -P (signed digits, see digits_kernel)
+    rec.x = load_u256(&bases[entry & 0x7FFFFFFFu].x);
+    rec.y = load_u256(&bases[entry & 0x7FFFFFFFu].y);
+    return signed_point(rec, entry);
+  };
+  auto take = [&](AffI& cur) -> bool {
+    const bool ident = affpacked_is_identity(pre);
+    cur = signed_point(pre, cur_idx);
+    // the unpacking above is done before the registers of `pre` are loaded again (the statement ties the 18 limbs)
+    asm volatile("" : "+v"(cur.x.l[0]), "+v"(cur.x.l[1]), "+v"(cur.x.l[2]), "+v"(cur.x.l[3]), "+v"(cur.x.l[4]),
+                      "+v"(cur.x.l[5]), "+v"(cur.x.l[6]), "+v"(cur.x.l[7]), "+v"(cur.x.l[8]), "+v"(cur.y.l[0]),
+                      "+v"(cur.y.l[1]), "+v"(cur.y.l[2]), "+v"(cur.y.l[3]), "+v"(cur.y.l[4]), "+v"(cur.y.l[5]),
+                      "+v"(cur.y.l[6]), "+v"(cur.y.l[7]), "+v"(cur.y.l[8]) :: "memory");
     cur_idx = next_idx;
+    if (i + 1 < cnt) {
+      pre.x = load_u256(&bases[cur_idx & 0x7FFFFFFFu].x);
+      pre.y = load_u256(&bases[cur_idx & 0x7FFFFFFFu].y);
+    }
     if (i + 2 < cnt) next_idx = idx[i + 2];
-    if (WHATIF == 1) {
-#pragma unroll
-      for (int l = 0; l < 8; ++l) {
-        acc.x.l[l] ^= rec.x.v[l];
-        acc.y.l[l] ^= rec.y.v[l];
+    ++i;
+    return ident;
+  };
+  while (i < cnt) {
+    // phase A: until the accumulator is a general point
+#pragma unroll 1
+    while (i < cnt && state != kMany) {
+      AffI cur;
+      const uint32_t this_idx = cur_idx;
+      if (take(cur)) continue;
+      if (state == kOne) {
+        MSM_ISA_MARK("begin affine_start");
+        bool vanished = false;
+        fe29 P, R;
+        pti_mmadd_head(acc.x, acc.y, cur.x, cur.y, P, R);
+        acc = pti_mmadd_tail(acc.x, acc.y, P, R, [&]() { return regather(this_idx); }, vanished);
+        state = vanished ? (uint32_t)kEmpty : (uint32_t)kMany;
+        MSM_ISA_MARK("end");
+      } else {
+        acc = pti_from_affi(cur);
+        state = kOne;
       }
-      continue;
     }
-    if (affpacked_is_identity(rec)) continue;   // an identity base adds nothing (one word tells: affi_pack)
-    AffI cur = affi_unpack_finite(rec);
-    {
-      // -y without the carry round (limbs < 2^30.5): y only ever multiplies the normalised ZZZ1, or enters the
-      // lifted subtraction of pti_mmadd (bounds: tools/fq29_bounds.py)
-      const fe29 ny = Fq29::neg_wide(cur.y);
-#pragma unroll
-      for (int l = 0; l < 9; ++l) cur.y.l[l] = negate ? ny.l[l] : cur.y.l[l];
-    }
-    if (state == kMany) {
+    // phase B: mixed additions only
+#pragma unroll 1
+    while (i < cnt) {
+      AffI cur;
+      const uint32_t this_idx = cur_idx;
+      if (take(cur)) continue;
       MSM_ISA_MARK("begin mixed_addition");
       bool vanished = false;
-      acc = pti_madd(acc, cur, vanished);
-      if (vanished) state = kEmpty;
+      fe29 U2, S2;
+      pti_madd_head(acc, cur.x, cur.y, U2, S2);   // cur dies here: its pins cost no copies
+      acc = pti_madd_tail(acc, U2, S2, [&]() { return regather(this_idx); }, vanished);
       MSM_ISA_MARK("end");
-    } else if (state == kOne) {   // second point of the item (wave-uniform in practice): affine + affine
-      MSM_ISA_MARK("begin affine_start");
-      bool vanished = false;
-      acc = pti_mmadd(acc.x, acc.y, cur, vanished);
-      state = vanished ? (uint32_t)kEmpty : (uint32_t)kMany;
-      MSM_ISA_MARK("end");
-    } else {
-      acc = pti_from_affi(cur);
-      state = kOne;
+      if (vanished) {
+        state = kEmpty;
+        break;
+      }
     }
   }
   if (size <= CH) {
@@ -114,34 +138,24 @@ accumulate_item(const uint32_t slot, const AffPacked* __restrict__ bases, const 
   }
 }
 
-template <bool PREFETCH, bool PIN, int WHATIF = 0>
-__device__ __forceinline__ void
-accumulate_body(const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,
-                const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,
-                const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,
-                uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials) {
-  accumulate_item<PREFETCH, PIN, WHATIF>(blockIdx.x * blockDim.x + threadIdx.x, bases, sorted, bucket_start, bucket_size,
-                                         item_start, win_base, order, counters, n, lb, CH, buckets, partials);
-}
-
 #define MSM_ACC_PARAMS const AffPacked* __restrict__ bases, const uint32_t* __restrict__ sorted,                       \
                        const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_size,           \
                        const uint32_t* __restrict__ item_start, const uint32_t* __restrict__ win_base,                \
                        const uint2* __restrict__ order, const PlanCounters* __restrict__ counters, uint32_t n,        \
                        uint32_t lb, uint32_t CH, PtI* __restrict__ buckets, PtI* __restrict__ partials
 #define MSM_ACC_FWD bases, sorted, bucket_start, bucket_size, item_start, win_base, order, counters, n, lb, CH, buckets, partials
-// accumulate_kernel<true>: two waves per SIMD (pinned), prefetch.  accumulate_kernel<false>: the same body without
-// prefetch and pin (a build for A/B runs; it needs 173 VGPRs, so it is a two-wave kernel too).
-template <bool LOW_OCC>
+// accumulate_kernel<true>: the shipped kernel (two waves per SIMD, pinned).  accumulate_kernel<false>: the same body
+// without the pin (MSM_AMD_LOW_OCC=0; it needs 180 VGPRs, so it is a two-wave kernel too).
+template <bool PIN>
 __global__ void __launch_bounds__(64) accumulate_kernel(MSM_ACC_PARAMS) {
-  accumulate_body<LOW_OCC, LOW_OCC>(MSM_ACC_FWD);
+  accumulate_item<PIN>(blockIdx.x * blockDim.x + threadIdx.x, MSM_ACC_FWD);
 }
-// Other builds of this kernel -- three waves per SIMD, the register-lean product-scanning form at four, the compiler's
-// column form at four with Y / ZZ / ZZZ parked in LDS, the hand-allocated five-wave statement of
-// tools/gen_accumulate_asm.py, and the what-if timing kernels -- were built, checked bit for bit and measured in round
-// 4 (profiles/r04_ab_accumulate_occupancy.txt); none is faster than the kernel above, so they only exist in
-// -DMSM_AMD_EXPERIMENTS builds (MSM_AMD_ACC_VARIANT selects one there).
+// Other builds of this kernel -- the single-loop shape of rounds 1-4, three waves per SIMD, the register-lean
+// product-scanning form at four, the compiler's column form at four with Y / ZZ / ZZZ parked in LDS, the hand-allocated
+// five-wave statement of tools/gen_accumulate_asm.py, the kernel on 128-byte wide records, and the what-if timing
+// kernels -- were built, checked bit for bit and measured in round 4 (profiles/r04_ab_accumulate_*.txt); none is faster
+// inside the pipeline than the kernel above, so they only exist in -DMSM_AMD_EXPERIMENTS builds (MSM_AMD_ACC_VARIANT
+// selects one there).
 #if defined(MSM_AMD_EXPERIMENTS)
 #include "experiments/k_accumulate_variants.inc"
 #endif
@@ -210,10 +224,23 @@ combine_big_kernel(const uint32_t* __restrict__ big_list, const PlanCounters* __
 // variant: 0 = three waves per SIMD (no prefetch), 1 = two waves per SIMD (register pin, prefetch), 2 = register-lean
 // (four waves per SIMD).  lds_bytes > 0 caps the resident workgroups per CU through the LDS allocation (160 KiB per
 // CU: 13 KiB per 64-lane workgroup = 12 waves per CU = 3 per SIMD), leaving register file for the other streams.
-void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
+void launch_accumulate(hipStream_t st, const Plan& p, const void* bases_any, int wide, const SortBuffers& b, PtI* buckets,
                        PtI* partials, int variant, uint32_t lds_bytes, hipEvent_t before_kernel, hipEvent_t after_kernel) {
   if (before_kernel) (void)hipEventRecord(before_kernel, st);
   const dim3 grid((unsigned)((p.max_items + 63) / 64)), block(64);
+  const AffPacked* bases = (const AffPacked*)bases_any;
+#if defined(MSM_AMD_EXPERIMENTS)
+  if (wide) {
+    hipLaunchKernelGGL(accumulate_kernel_wide, grid, block, lds_bytes, st, (const AffWide*)bases_any,
+                       (const uint32_t*)b.sorted, (const uint32_t*)b.bucket_start, (const uint32_t*)b.bucket_size,
+                       (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, (const uint2*)b.order,
+                       (const PlanCounters*)b.counters, p.n, p.lb, p.CH, buckets, partials);
+    if (after_kernel) (void)hipEventRecord(after_kernel, st);
+    return;
+  }
+#else
+  (void)wide;
+#endif
 #define MSM_ACC_ARGS bases, (const uint32_t*)b.sorted, (const uint32_t*)b.bucket_start, (const uint32_t*)b.bucket_size, \
                      (const uint32_t*)b.item_start, (const uint32_t*)b.win_items, (const uint2*)b.order,                \
                      (const PlanCounters*)b.counters, p.n, p.lb, p.CH, buckets, partials
@@ -237,6 +264,8 @@ void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, co
     hipLaunchKernelGGL(accumulate_whatif_math, grid, block, lds_bytes, st, MSM_ACC_ARGS);
   } else if (variant == 12) {
     hipLaunchKernelGGL(accumulate_whatif_math_w3, grid, block, lds_bytes, st, MSM_ACC_ARGS);
+  } else if (variant == 7) {
+    hipLaunchKernelGGL(accumulate_kernel_r4, grid, block, lds_bytes, st, MSM_ACC_ARGS);
   } else
 #endif
   if (variant == 1) {

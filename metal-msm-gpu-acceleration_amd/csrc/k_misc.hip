@@ -43,6 +43,18 @@ convert_bases_kernel(const Affine* __restrict__ in, uint32_t n, AffPacked* __res
   store_affi(&out[t], affi_from_ext(load_affine(&in[t])));
 }
 
+#if defined(MSM_AMD_EXPERIMENTS)
+// The same into the wide record (one 128-byte line per base: x, y, -y as limbs; bn254_ec29.hip.h AffWide) -- accumulate
+// variant 8 of the experiments build.
+__global__ void __launch_bounds__(128)
+convert_bases_wide_kernel(const Affine* __restrict__ in, uint32_t n, AffWide* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(kFrontPriority);
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  store_wide(&out[t], affi_widen(affi_from_ext(load_affine(&in[t]))));
+}
+#endif
+
 // Precomputed window tables: tables[w * n + i] = 2^(c w) P_i for w = 0 .. W-1, in the packed internal
 // form, so that window w of scalar i adds into the SAME bucket set as window 0: one set of 2^(c-1) buckets serves
 // all windows and c can grow to 18..20 (about 18 % fewer additions at 2^20 points).  One thread per point walks the
@@ -86,6 +98,12 @@ void launch_build_tables(hipStream_t st, const Affine* in, uint32_t n, uint32_t 
 void launch_convert_bases(hipStream_t st, const Affine* in, uint32_t n, AffPacked* out) {
   hipLaunchKernelGGL(convert_bases_kernel, dim3((n + 127) / 128), dim3(128), 0, st, in, n, out);
 }
+
+#if defined(MSM_AMD_EXPERIMENTS)
+void launch_convert_bases_wide(hipStream_t st, const Affine* in, uint32_t n, AffWide* out) {
+  hipLaunchKernelGGL(convert_bases_wide_kernel, dim3((n + 127) / 128), dim3(128), 0, st, in, n, out);
+}
+#endif
 
 void launch_projective_to_affine(hipStream_t st, const Jacobian* in, uint32_t n, Affine* out) {
   hipLaunchKernelGGL(projective_to_affine_kernel, dim3((n + 63) / 64), dim3(64), 0, st, in, n, out);

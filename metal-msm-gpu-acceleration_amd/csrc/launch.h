@@ -71,7 +71,8 @@ void launch_be32_to_le(hipStream_t st, const uint32_t* in, size_t words, uint32_
 void launch_ark_affine_to_affine(hipStream_t st, const uint8_t* in, uint32_t n, Affine* out);
 
 // k_accumulate.hip
-void launch_accumulate(hipStream_t st, const Plan& p, const AffPacked* bases, const SortBuffers& b, PtI* buckets,
+// bases: AffPacked records; wide != 0 (experiments build, variant 8): AffWide records
+void launch_accumulate(hipStream_t st, const Plan& p, const void* bases, int wide, const SortBuffers& b, PtI* buckets,
                        PtI* partials, int variant, uint32_t lds_bytes, hipEvent_t before_kernel, hipEvent_t after_kernel);
 
 void launch_combine(hipStream_t st, const Plan& p, const SortBuffers& b, PtI* buckets, PtI* partials);
@@ -91,6 +92,9 @@ void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, const uint
 // k_misc.hip
 void launch_projective_to_affine(hipStream_t st, const Jacobian* in, uint32_t n, Affine* out);
 void launch_convert_bases(hipStream_t st, const Affine* in, uint32_t n, AffPacked* out);
+#if defined(MSM_AMD_EXPERIMENTS)
+void launch_convert_bases_wide(hipStream_t st, const Affine* in, uint32_t n, AffWide* out);
+#endif
 void launch_gen_instance(hipStream_t st, uint64_t seed, uint32_t n, int scalars_mont, Affine* bases, u256* scalars);
 
 // k_stage.hip

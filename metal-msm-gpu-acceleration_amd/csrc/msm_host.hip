@@ -172,7 +172,7 @@ struct msm_amd_ctx {
                                          // queues HIP gives a process -- main, front, two reduce -- share a queue
                                          // with the accumulate grid and wait behind it: measured, 1.6x slower.)
   bool alt_reduce = true;                // MSM_AMD_ALT_REDUCE=0: one reduce stream
-  int acc_variant = 1;                   // accumulate kernel build (launch_accumulate): 0 three waves/SIMD, 1 two, 2 register-lean
+  int acc_variant = 1;                   // accumulate kernel build (launch_accumulate): 1 shipped, 0 without the register pin; experiments build: 2..12
   uint32_t acc_lds = 0;                  // LDS bytes per accumulate workgroup: caps its waves per CU (MSM_AMD_ACC_LDS)
   uint32_t seq = 0;
   hipStream_t front_stream = nullptr;    // side stream: conversion, digits, sort, work-item planning
@@ -801,7 +801,15 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   if ((rc = ensure(ctx, w.counters, sizeof(PlanCounters)))) return rc;
   const bool prepared = point_layout == MSM_AMD_POINT_PREPARED || tb != nullptr;
   AffPacked* const fill = prepared ? nullptr : ctx->convert_into;   // bases cache fill: convert straight into the entry
-  if (!prepared && !fill && (rc = ensure(ctx, w.bases29, n * sizeof(AffPacked)))) return rc;
+#if defined(MSM_AMD_EXPERIMENTS)
+  // variant 8: bases converted inside this call go into WIDE records (128 B: x, y, -y as limbs)
+  const bool wide = !prepared && !fill && ctx->acc_variant == 8;
+  const size_t base_record = wide ? sizeof(AffWide) : sizeof(AffPacked);
+#else
+  const bool wide = false;
+  const size_t base_record = sizeof(AffPacked);
+#endif
+  if (!prepared && !fill && (rc = ensure(ctx, w.bases29, n * base_record))) return rc;
   if ((rc = ensure(ctx, w.buckets, p.total_buckets * sizeof(PtI)))) return rc;
   if ((rc = ensure(ctx, w.item_partials, p.max_items * sizeof(PtI)))) return rc;
   SortBuffers sb{};
@@ -860,7 +868,10 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   const AffPacked* bases = tb ? (const AffPacked*)tb->d_tables
                               : (prepared ? (const AffPacked*)d_points
                                           : (fill ? (const AffPacked*)fill : (const AffPacked*)w.bases29.p));
-  if (!prepared)   // external 8 x u32 -> packed internal domain
+#if defined(MSM_AMD_EXPERIMENTS)
+  if (wide) launch_convert_bases_wide(fs, pts, p.n, (AffWide*)w.bases29.p);
+#endif
+  if (!prepared && !wide)   // external 8 x u32 -> packed internal domain
     launch_convert_bases(fs, pts, p.n, fill ? fill : (AffPacked*)w.bases29.p);
   HIP_TRY(ctx, hipEventRecord(slot.ev[EV_CONVERT], fs));
   launch_digits(fs, p, sc, sc_mont, sb.digits);
@@ -878,7 +889,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
     if (rs != st) HIP_TRY(ctx, hipStreamWaitEvent(st, w.reduce_done, 0));
     w.reduce_pending = false;
   }
-  launch_accumulate(st, p, bases, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p,
+  launch_accumulate(st, p, bases, wide ? 1 : 0, sb, (PtI*)w.buckets.p, (PtI*)w.item_partials.p,
                     ctx->acc_variant, ctx->acc_lds, slot.ev[EV_ACC_K0], slot.ev[EV_ACC_K1]);
   HIP_TRY(ctx, hipEventRecord(w.acc_done, st));
   w.acc_pending = true;

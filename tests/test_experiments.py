@@ -42,7 +42,7 @@ def test_unshipped_multiplication_forms_on_the_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [3, 2, 5, 4])
+@pytest.mark.parametrize("variant", [3, 2, 5, 4, 7, 8])
 def test_accumulate_kernel_variants_agree_with_the_oracle(variant):
     """Whole MSMs (sizes 1 .. 1000, every window size, skewed and edge inputs incl. identity bases and cancelling
     points -- the redo pass of variant 4 --, the table pipeline) through each experimental accumulate kernel."""

@@ -84,9 +84,29 @@ def tally(body):
     is picked up again by the region that holds its "resume" mark; the region holding "end" closes it."""
     header = next(i for i, ln in enumerate(body) if "This Inner Loop Header" in ln)
     out = collections.defaultdict(collections.Counter)
+    # pass 0: the exceptional-case code is skipped as a whole -- the stretch that the closest `s_cbranch_execz` above a
+    # "rare" mark jumps over.  (A mark drifts inside its basic block: it may sit at the END of the exact-zero test it
+    # announces; until round 4 the 171 multiplier instructions of that test were counted into the affine start.)
+    label_at = {}
+    for i, ln in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", ln.strip())
+        if m:
+            label_at[m.group(1)] = i
+    rare_line = [False] * len(body)
+    for r, ln in enumerate(body):
+        if "MSM_MARK rare" not in ln:
+            continue
+        for i in range(r, -1, -1):
+            m = re.match(r"^\s*s_cbranch_execz\s+(\.LBB\d+_\d+)", body[i])
+            if m and label_at.get(m.group(1), -1) > r:
+                for k in range(i + 1, label_at[m.group(1)]):
+                    rare_line[k] = True
+                break
     # pass 1: regions as lists of (kind, payload) events
     regs, cur = [], []
-    for ln in body[header:]:
+    for off, ln in enumerate(body[header:]):
+        if rare_line[header + off]:
+            continue
         s = ln.strip()
         m = re.match(r"^; MSM_MARK (\w+)\s*(\w*)", s)
         if m:
@@ -140,8 +160,18 @@ def main(src, dst):
         if "accumulate_kernel" not in name or "accumulate_kernel_park" in name or "accumulate_kernel_asm" in name:
             continue   # (the experimental builds with other code shapes are not tallied)
         lean = "accumulate_kernel_lean" in name
-        variant = "lean_4_waves" if lean else ("low_occupancy_2_waves" if "ILb1E" in name else "3_waves")
-        pc = tally(body)
+        if lean:
+            variant = "lean_4_waves"
+        elif "accumulate_kernelILb1E" in name:
+            variant = "low_occupancy_2_waves"       # the shipped kernel
+        elif "accumulate_kernelILb0E" in name:
+            variant = "without_register_pin"
+        else:
+            variant = re.sub(r"^_ZN7msm_amd\d+", "", name)[:40]   # experiments build: keyed by symbol
+        try:
+            pc = tally(body)
+        except StopIteration:
+            continue
         hoisted = collections.Counter({k: v for k, v in pc["hoisted"].items()})
         hoisted_mult = sum(hoisted[k] for k in MULT)
         madd = pc["mixed_addition"] + (hoisted if hoisted_mult else collections.Counter())
@@ -152,9 +182,9 @@ def main(src, dst):
             # the exact-zero test's multiplication floats above its "rare" mark in this build: 171 of the count
             # belong to the exceptional block
             pass
-        elif not 1400 <= ms["multiplier"] <= 1700:
+        elif ms["multiplier"] and not 1400 <= ms["multiplier"] <= 1700:
             raise SystemExit(f"{name}: mixed addition counts {ms['multiplier']} multiplier instructions, expected ~1548")
-        if not lean and not 780 <= as_["multiplier"] <= 1100:
+        if not lean and as_["multiplier"] and not 780 <= as_["multiplier"] <= 1100:
             raise SystemExit(f"{name}: affine start counts {as_['multiplier']} multiplier instructions, expected ~864")
         out["kernels"][variant] = {"symbol": name, "mixed_addition": ms, "affine_start": as_,
                                    "hoisted_above_the_path_split": summarise(hoisted)}
