@@ -47,5 +47,5 @@ def test_accumulate_kernel_variants_agree_with_the_oracle(variant):
     """Whole MSMs (sizes 1 .. 1000, every window size, skewed and edge inputs incl. identity bases and cancelling
     points -- the redo pass of variant 4 --, the table pipeline) through each experimental accumulate kernel."""
     _child(["tests/test_gpu_msm.py", "-m", "gpu", "-k",
-            "small or window_sizes or edge_scalars or skewed or zero_scalars or known_answers or precomputed_window"],
+            "small or window_sizes or edge_scalars or skewed or zero_scalars or known_answers or precomputed_window or doubling_inside"],
            {"MSM_AMD_ACC_VARIANT": str(variant)}, 600)

@@ -308,6 +308,31 @@ def test_known_answers_without_the_oracle(cfg, msm_pkg):
     assert o.decode_jacobian_mont_le(msm_pkg.gpu_msm_h2c(sb, pb, cfg)) == g3
 
 
+@pytest.mark.parametrize("c", [0, 5, 15])
+def test_doubling_inside_the_mixed_addition_gathers_the_base_again(cfg, msm_pkg, c):
+    """The exceptional case q == p of the MIXED addition (accumulator already a general point): the accumulate kernel has
+    given q's registers to the next gather by then and gathers q again (pti_madd_tail's reload, k_accumulate.hip).  Bases
+    P, P, 2P, 4P, 8P with one scalar share every bucket: P -> (affine start, doubling) 2P -> (mixed addition, doubling)
+    4P -> 8P -> 16P; with the scalar r - k every digit changes sign and the re-gathered base must be negated again.
+    Surrounded by ordinary points so that the items have neighbours in their waves."""
+    pts, sc = small_instance(31, 120)
+    P = pts[0]
+    chain = [P, P] + [o.scalar_mul(2 ** j, P) for j in (1, 2, 3)]
+    for k in (1, 5, (1 << 14) + 1, o.R_ORDER - 5, o.R_ORDER - (1 << 33) - 7):
+        allp = pts[1:60] + chain + pts[60:]
+        alls = sc[1:60] + [k] * len(chain) + sc[60:]
+        sb, pb = h2c_instance_bytes(allp, alls)
+        cfg.set_window_size(c)
+        try:
+            out = msm_pkg.gpu_msm_h2c(sb, pb, cfg)
+        finally:
+            cfg.set_window_size(0)
+        assert o.decode_jacobian_mont_le(out) == o.msm_naive(alls, allp), (c, k)
+    # the chain alone: every bucket it touches holds nothing else
+    sb, pb = h2c_instance_bytes(chain, [7] * len(chain))
+    assert o.decode_jacobian_mont_le(msm_pkg.gpu_msm_h2c(sb, pb, cfg)) == o.scalar_mul(7 * 16, P)
+
+
 @pytest.mark.parametrize("c", [0, 5, 15, 16, 17])
 def test_canonical_scalars_at_or_above_r_are_reduced(cfg, msm_pkg, c):
     """Raw 256-bit integers in the canonical layouts (instance files, FFI callers) may exceed r; the result must be
