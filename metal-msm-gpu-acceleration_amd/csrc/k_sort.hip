@@ -19,11 +19,17 @@ constexpr int kSortThreads = 1024;       // hist / plan / scatter workgroup size
 // reference de-Montgomerys on the CPU, limbs_conversion.rs:282-288), 0 = canonical integer.
 // D = uint16_t (c <= 15: the per-call pipeline) or uint32_t (c <= 24: precomputed window tables, where the
 // [W][n] digit matrix is consumed as ONE window of W * n entries, see make_table_plan in msm_host.hip).
-template <typename D>
+// C > 0: window size and window count are compile-time constants (c = C, W = 254 / C + 1): the window loop unrolls
+// and every digit is one v_alignbit + v_and on fixed words of the scalar instead of a 16-way select chain over a
+// run-time word index (the common window sizes of the pipelined policy; 375 -> ~140 instructions per scalar).
+// C = 0: c and W from the arguments.
+template <typename D, int C = 0>
 __global__ void __launch_bounds__(256)
-digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W, int scalars_mont,
+digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c_arg, uint32_t W_arg, int scalars_mont,
               D* __restrict__ digits) {
   constexpr uint32_t kSignShift = 8 * sizeof(D) - 1;
+  const uint32_t c = C > 0 ? (uint32_t)C : c_arg;
+  const uint32_t W = C > 0 ? (uint32_t)(254 / (C > 0 ? C : 1) + 1) : W_arg;
   __builtin_amdgcn_s_setprio(kFrontPriority);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -38,6 +44,7 @@ digits_kernel(const u256* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t
   }
   const uint32_t half = 1u << (c - 1);
   uint32_t carry = 0;
+#pragma unroll
   for (uint32_t w = 0; w < W; ++w) {
     const uint32_t start = w * c;
     uint32_t v = (start < 256 ? u256_extract_bits(k, start, c) : 0u) + carry;
@@ -129,6 +136,19 @@ coarse_prefix_kernel(uint32_t* __restrict__ coarse_cnt, uint32_t Q, uint32_t nhi
 // Same-key lanes are ranked in lane order, so the pass is stable.  north_star: "wavefront ballot/prefix-sum for
 // bucket index sorting"; A/B against the plain returning-atomic ranking: profiles/r02_sort_ranking_ab.txt.
 __device__ __forceinline__ uint32_t wave_claim(uint32_t key, uint32_t bits, bool valid, uint32_t* cursors) {
+#if defined(MSM_AMD_CLAIM2)
+  // the same mask with 6 instead of 8 VALU instructions per key bit: s = -bit (one v_bfe_i32), lanes agree with the
+  // ballot where ~(ballot ^ s) is set (v_xnor), 32 bits at a time
+  const uint64_t peers0 = __ballot(valid);
+  uint32_t lo = (uint32_t)peers0, hi = (uint32_t)(peers0 >> 32);
+#pragma unroll 1
+  for (uint32_t b = 0; b < bits; ++b) {
+    const int32_t s = __builtin_amdgcn_sbfe((int32_t)key, b, 1u);   // 0 or -1
+    const uint64_t bal = __ballot(s != 0);
+    lo &= ~((uint32_t)bal ^ (uint32_t)s);
+    hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)s);
+  }
+#else
   uint64_t peers = __ballot(valid);
 #pragma unroll 1
   for (uint32_t b = 0; b < bits; ++b) {
@@ -137,6 +157,7 @@ __device__ __forceinline__ uint32_t wave_claim(uint32_t key, uint32_t bits, bool
     peers &= bit ? bal : ~bal;
   }
   const uint32_t lo = (uint32_t)peers, hi = (uint32_t)(peers >> 32);
+#endif
   const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
   const uint32_t count = __popc(lo) + __popc(hi);
   const uint32_t leader = lo ? (uint32_t)__builtin_ctz(lo) : 32u + (uint32_t)__builtin_ctz(hi | 0x80000000u);
@@ -771,6 +792,16 @@ int sort_set_attributes(const char** failed) {
 
 void launch_digits(hipStream_t st, const Plan& p, const u256* scalars, int scalars_mont, void* digits) {
   const dim3 grid((p.n_scalars + 255) / 256), block(256);
+#define LAUNCH_DIGITS_C(D, CC)                                                                                      \
+  hipLaunchKernelGGL((digits_kernel<D, CC>), grid, block, 0, st, scalars, p.n_scalars, p.c, p.W_digits, scalars_mont, \
+                     (D*)digits)
+  if (p.W_digits == 254 / p.c + 1) {   // (always so; the specialisations compute W from C)
+    if (p.wide_digits && p.c == 17) { LAUNCH_DIGITS_C(uint32_t, 17); return; }
+    if (p.wide_digits && p.c == 16) { LAUNCH_DIGITS_C(uint32_t, 16); return; }
+    if (!p.wide_digits && p.c == 15) { LAUNCH_DIGITS_C(uint16_t, 15); return; }
+    if (!p.wide_digits && p.c == 13) { LAUNCH_DIGITS_C(uint16_t, 13); return; }
+  }
+#undef LAUNCH_DIGITS_C
   if (p.wide_digits)
     hipLaunchKernelGGL(digits_kernel<uint32_t>, grid, block, 0, st, scalars, p.n_scalars, p.c, p.W_digits, scalars_mont,
                        (uint32_t*)digits);
