@@ -136,9 +136,9 @@ coarse_prefix_kernel(uint32_t* __restrict__ coarse_cnt, uint32_t Q, uint32_t nhi
 // Same-key lanes are ranked in lane order, so the pass is stable.  north_star: "wavefront ballot/prefix-sum for
 // bucket index sorting"; A/B against the plain returning-atomic ranking: profiles/r02_sort_ranking_ab.txt.
 __device__ __forceinline__ uint32_t wave_claim(uint32_t key, uint32_t bits, bool valid, uint32_t* cursors) {
-#if defined(MSM_AMD_CLAIM2)
-  // the same mask with 6 instead of 8 VALU instructions per key bit: s = -bit (one v_bfe_i32), lanes agree with the
-  // ballot where ~(ballot ^ s) is set (v_xnor), 32 bits at a time
+  // lanes that agree with this lane on every key bit: s = -bit (one v_bfe_i32); ~(ballot ^ s) keeps the lanes whose
+  // bit equals this lane's (the compiler fuses the and-xnor into one v_bitop3_b32 per half: 4 VALU instructions per
+  // key bit; the select  peers &= bit ? bal : ~bal  on a 64-bit mask took 8)
   const uint64_t peers0 = __ballot(valid);
   uint32_t lo = (uint32_t)peers0, hi = (uint32_t)(peers0 >> 32);
 #pragma unroll 1
@@ -148,16 +148,6 @@ __device__ __forceinline__ uint32_t wave_claim(uint32_t key, uint32_t bits, bool
     lo &= ~((uint32_t)bal ^ (uint32_t)s);
     hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)s);
   }
-#else
-  uint64_t peers = __ballot(valid);
-#pragma unroll 1
-  for (uint32_t b = 0; b < bits; ++b) {
-    const bool bit = (key >> b) & 1u;
-    const uint64_t bal = __ballot(bit);
-    peers &= bit ? bal : ~bal;
-  }
-  const uint32_t lo = (uint32_t)peers, hi = (uint32_t)(peers >> 32);
-#endif
   const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
   const uint32_t count = __popc(lo) + __popc(hi);
   const uint32_t leader = lo ? (uint32_t)__builtin_ctz(lo) : 32u + (uint32_t)__builtin_ctz(hi | 0x80000000u);
