@@ -224,6 +224,27 @@ def main(argv=None):
         red_ms.append(t.reduce_ms)
         fin_ms.append(t.final_ms)
 
+    # Device state under this load (rank 0): rocm-smi asked for shader clock and package power while the pre-warm and
+    # warm-up steps run -- the same pipelined load as the timed steps, but OUTSIDE the timed region, so the child
+    # processes cannot touch `value`.  The pipeline is power-limited (profiles/r04_clock_power_during_bench.txt): the
+    # clock it actually runs at belongs beside peaks that are quoted at the nominal 2.4 GHz.  Never an error.
+    state_samples, state_stop = [], None
+    def sample_device_state():
+        import re
+        import subprocess
+        while not state_stop.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json", "-d", str(gpu_index)],
+                                   capture_output=True, text=True, timeout=10)
+                card = next(iter(json.loads(r.stdout).values()))
+                clk = re.search(r"(\d+)\s*Mhz", card.get("sclk clock speed:", ""), re.I)
+                pw = next((v for k, v in card.items() if "Power" in k and "(W)" in k), None)
+                if clk:
+                    state_samples.append((int(clk.group(1)), None if pw is None else float(pw)))
+            except Exception:   # noqa: BLE001 -- no rocm-smi, another output format: the field stays null
+                return
+    state_thread = None
+
     cold_value = None
     if args.prewarm_steps > 0:
         # what the plain (W warm-up, K timed) recipe gives on a device whose clocks have not ramped up yet -- reported
@@ -234,7 +255,19 @@ def main(argv=None):
         run_steps(args.steps, lambda t: None)
         barrier()
         cold_value = inst * world * args.steps / (time.perf_counter() - tc0)
+        if rank == 0 and not args.no_extras:
+            import threading
+            state_stop = threading.Event()
+            state_thread = threading.Thread(target=sample_device_state, daemon=True)
+            state_thread.start()
         run_steps(args.prewarm_steps, lambda t: None)    # clocks up before anything is counted (not warm-up STEPS: the
+        if state_thread is not None:                     # (keep the load up until rocm-smi has answered at least twice)
+            extra = 0
+            while len(state_samples) < 2 and state_thread.is_alive() and extra < 40:
+                run_steps(8, lambda t: None)
+                extra += 1
+            state_stop.set()
+            state_thread.join(timeout=15)
     outs = run_steps(args.warmup, lambda t: None)        # W steps are still run, the K steps still timed alone)
     barrier()
     t0 = time.perf_counter()
@@ -424,6 +457,12 @@ def main(argv=None):
             "warmup": args.warmup,
             "device_prewarm_steps": args.prewarm_steps,   # untimed load before the warm-up steps (GPU clock ramp), see --help
             "value_without_prewarm": None if cold_value is None else round(cold_value, 3),   # same W, same K, cold clocks
+            "device_state_under_load": None if not state_samples else {
+                "sclk_mhz": [c for c, _ in state_samples],
+                "package_power_w": [w for _, w in state_samples],
+                "source": "rocm-smi --showclocks --showpower --json, asked while the pre-warm steps run (the same "
+                          "pipelined load as the timed steps, outside the timed region); the roofline peaks are quoted "
+                          "at the nominal 2.4 GHz"},
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",

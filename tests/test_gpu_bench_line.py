@@ -46,3 +46,9 @@ def test_bench_prints_one_contract_line():
     assert d["e2e_host_slices_bases_cache_MSM_per_s"] > d["e2e_host_slices_MSM_per_s"] > 50
     assert d["product_cpu_msm"]["byte_identical_to_gpu_result"] is True
     assert isinstance(d["cli_system_runtime"]["e2e_host_slices_bases_cache_MSM_per_s"], float)
+    # late round 4: the clock and package power the device runs this load at (rocm-smi, outside the timed region); the
+    # field is null where rocm-smi does not answer, never an error
+    assert "device_state_under_load" in x
+    st = x["device_state_under_load"]
+    if st is not None:
+        assert len(st["sclk_mhz"]) >= 1 and all(500 < c < 3000 for c in st["sclk_mhz"])
