@@ -305,30 +305,41 @@ MSM_HD PtI pti_mmadd(const fe29& px, const fe29& py, const AffI& q) {
 }
 
 // p + q, both XYZZ, neither the identity.  add-2008-s, 12M + 2S.
-MSM_HD PtI pti_add_nz(const PtI& p, const PtI& q) {
-  const fe29 U1 = Fq29::mul(p.x, q.zz);
-  const fe29 U2 = Fq29::mul(q.x, p.zz);
-  const fe29 S1 = Fq29::mul(p.y, q.zzz);
-  const fe29 S2 = Fq29::mul(q.y, p.zzz);
-  const fe29 P = Fq29::norm(Fq29::sub<K4E30>(U2, U1));     // < 5.2 p
-  const fe29 R = Fq29::norm(Fq29::sub<K4E30>(S2, S1));     // < 5.1 p
-  if (Fq29::maybe_zero(P, 6)) {
-    if (Fq29::is_zero_exact(P)) {
-      if (Fq29::is_zero_exact(R)) return pti_double(p);
+MSM_HD PtI pti_add_nz(const PtI& p_in, const PtI& q_in, bool& vanished) {
+  // pins once per basic block, multiplications without pins of their own (see pti_madd_head)
+  PtI p, q;
+  p.x = pin_limbs(p_in.x); p.y = pin_limbs(p_in.y); p.zz = pin_limbs(p_in.zz); p.zzz = pin_limbs(p_in.zzz);
+  q.x = pin_limbs(q_in.x); q.y = pin_limbs(q_in.y); q.zz = pin_limbs(q_in.zz); q.zzz = pin_limbs(q_in.zzz);
+  const fe29 U1a = Fq29::mul_np(p.x, q.zz);
+  const fe29 U2 = Fq29::mul_np(q.x, p.zz);
+  const fe29 S1a = Fq29::mul_np(p.y, q.zzz);
+  const fe29 S2 = Fq29::mul_np(q.y, p.zzz);
+  const fe29 P0 = Fq29::norm(Fq29::sub<K4E30>(U2, U1a));     // < 5.2 p
+  const fe29 R0 = Fq29::norm(Fq29::sub<K4E30>(S2, S1a));     // < 5.1 p
+  if (Fq29::maybe_zero(P0, 6)) {
+    if (Fq29::is_zero_exact(P0)) {
+      if (Fq29::is_zero_exact(R0)) return pti_double(p);
+      vanished = true;   // q == -p
       return pti_identity();
     }
   }
-  const fe29 PP = Fq29::sqr(P);
-  const fe29 PPP = Fq29::mul(P, PP);
-  const fe29 Q = Fq29::mul(U1, PP);
-  const fe29 RR = Fq29::sqr(R);
+  const fe29 P = pin_limbs(P0), R = pin_limbs(R0), U1 = pin_limbs(U1a), S1 = pin_limbs(S1a), ZZ1 = pin_limbs(p.zz),
+             ZZ2 = pin_limbs(q.zz), ZZZ1 = pin_limbs(p.zzz), ZZZ2 = pin_limbs(q.zzz);
+  const fe29 PP = Fq29::sqr_np(P);
+  const fe29 PPP = Fq29::mul_np(P, PP);
+  const fe29 Q = Fq29::mul_np(U1, PP);
+  const fe29 RR = Fq29::sqr_np(R);
   PtI r;
   r.x = Fq29::norm(Fq29::sub<K8E31>(RR, Fq29::add(PPP, Fq29::add(Q, Q))));               // < 9.2 p
   const fe29 T = Fq29::sub<K16E30>(Q, r.x);      // un-normalised, like -PPP (see pti_madd)   // < 17.1 p
-  r.y = Fq29::mul2(R, T, S1, Fq29::neg_wide(PPP));    // R*T - S1*PPP in one reduction         // < 1.2 p
-  r.zz = Fq29::mul(Fq29::mul(p.zz, q.zz), PP);
-  r.zzz = Fq29::mul(Fq29::mul(p.zzz, q.zzz), PPP);
+  r.y = Fq29::mul2_np(R, T, S1, Fq29::neg_wide(PPP));    // R*T - S1*PPP in one reduction      // < 1.2 p
+  r.zz = Fq29::mul_np(Fq29::mul_np(ZZ1, ZZ2), PP);
+  r.zzz = Fq29::mul_np(Fq29::mul_np(ZZZ1, ZZZ2), PPP);
   return r;
+}
+MSM_HD PtI pti_add_nz(const PtI& p, const PtI& q) {
+  bool vanished = false;
+  return pti_add_nz(p, q, vanished);
 }
 
 // General addition with identity operands allowed.

@@ -32,7 +32,7 @@ struct GroupJob {
 
 // The row-sum job and the column-sum job of one level in ONE launch (they are independent; a launch costs more
 // queueing behind the resident accumulate grid than the additions themselves).  One lane per output; both operands
-// of every addition die in it (<= 168 VGPRs).
+// of every addition die in it (184 VGPRs, two waves per SIMD: it takes the place of an accumulate wave, it does not fit beside two).
 __global__ void __launch_bounds__(64)
 sum_groups_kernel(GroupJob j0, GroupJob j1) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

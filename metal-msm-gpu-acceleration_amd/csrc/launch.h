@@ -81,7 +81,7 @@ void launch_combine(hipStream_t st, const Plan& p, const SortBuffers& b, PtI* bu
 int reduce_set_attributes(const char** failed);
 constexpr uint32_t kReduceGroup = 16;      // pipelined instances: chains of 15 additions, two levels at lb = 16
 constexpr uint32_t kReduceGroupMin = 4;    // a lone call trades launches for shorter chains (launch_reduce picks per level)
-constexpr size_t kReduceResidentLanes = 160 * 1024;   // sum_groups_kernel: 172 VGPRs, 2 waves/SIMD = 131 k lanes per round (a lone call's level picks the smallest group whose outputs stay near that)
+constexpr size_t kReduceResidentLanes = 160 * 1024;   // sum_groups_kernel: 184 VGPRs, 2 waves/SIMD = 131 k lanes per round (a lone call's level picks the smallest group whose outputs stay near that)
 size_t reduce_scratch_elems(uint32_t lb);   // PtI elements of S and of T per window (sized for kReduceGroupMin)
 // bucket_size: [W][nb] point counts (zero = the bucket was never written and counts as the identity), or nullptr
 // when every bucket holds a valid point (stage entry point sum_reduction)
