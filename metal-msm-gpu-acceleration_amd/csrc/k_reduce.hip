@@ -96,7 +96,14 @@ reduce_bits_kernel(const PtI* __restrict__ C, const PtI* __restrict__ R, uint32_
   if (threadIdx.x == 0) store_jac(&out[(size_t)w * (lb + 1) + k], pti_to_ext(load_pti(&sh[0])));
 }
 
-static uint32_t reduce_bits_threads(uint32_t lb) {
+// Threads of one bit-subset sum.  A lone call wants the shortest dependency chain (one summand per thread, then the LDS
+// tree).  A pipelined instance (Plan::rb_threads = 64) wants ONE wave per sum: a workgroup of two or more 182-VGPR waves
+// needs that many free wave slots on one CU at once while the accumulate grid of the next instance owns the machine --
+// with one wave the reduce span of an instance drops from 1.39 to 0.88 ms at the same throughput
+// (profiles/r04_reduce_bits_one_wave.txt).
+static uint32_t reduce_bits_threads(const Plan& p) {
+  if (p.rb_threads) return p.rb_threads;
+  const uint32_t lb = p.lb;
   const uint32_t longest = 1u << ((lb + 1) / 2);
   uint32_t t = 64;
   while (t < 512 && t < longest / 2) t <<= 1;
@@ -191,8 +198,8 @@ void launch_reduce(hipStream_t st, const Plan& p, const PtI* buckets, const uint
     }
   }
   // job[fam].src now points at [W][rows] sums
-  hipLaunchKernelGGL(reduce_bits_kernel, dim3(p.lb + 1, p.W), dim3(reduce_bits_threads(p.lb)),
-                     reduce_bits_threads(p.lb) * sizeof(PtI), st, job[1].src, job[0].src, L, H, partial);
+  hipLaunchKernelGGL(reduce_bits_kernel, dim3(p.lb + 1, p.W), dim3(reduce_bits_threads(p)),
+                     reduce_bits_threads(p) * sizeof(PtI), st, job[1].src, job[0].src, L, H, partial);
 }
 
 }  // namespace msm_amd

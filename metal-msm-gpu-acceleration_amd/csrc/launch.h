@@ -28,6 +28,7 @@ struct Plan {
   uint32_t front_threads;     // workgroup size of the sort / planning kernels (256..1024)
   uint32_t CH;                // accumulate: max points per work item (bucket chunk)
   uint32_t red_L, red_H;      // reduce: column / row bits of the slot index (L = ceil(lb / 2), H = lb - L)
+  uint32_t rb_threads;        // reduce: threads per bit-subset sum (0 = by the sum's length; 64 for pipelined instances)
   uint32_t red_group;         // reduce: additions per lane and level of the row / column sums (kReduceGroupMin..16)
   size_t total_buckets, total_segs, partial_count, max_items;
 };

@@ -770,6 +770,7 @@ int enqueue_msm(msm_amd_ctx* ctx, Workspace& w, InstanceSlot& slot, int scalar_l
   const uint32_t c = tb ? tb->c : (ctx->forced_window ? ctx->forced_window : (lone ? auto_window_lone(n) : auto_window(n)));
   Plan p = tb ? make_plan(n, c, tb->W) : make_plan(n, c);
   if (lone) p.red_group = pick_reduce_group(p);   // (pipelined small instances: 2^16 -6 %, 2^18 +3 % -- not taken)
+  p.rb_threads = lone ? 0u : 64u;                 // one wave per bit-subset sum beside a resident accumulate grid (k_reduce.hip)
   // the tile-staged scatter (1024-thread workgroups, 60 VGPRs, 64 KB of LDS) is for a sort that has the machine to
   // itself; beside a resident accumulate grid it is slower than the plain scatter (4 x 2^22 points: 6.15 vs 5.65 ms per MSM)
   if (!lone && !std::getenv("MSM_AMD_TILED")) p.tiled = 0;
